@@ -1,0 +1,80 @@
+// agz_nn.h -- the dual-head ResNet of AlphaGo.jl as resident HIP state + hand-written
+// gfx950 kernels (inference only).  Topology: /root/reference/src/neural_net.jl:13-33,57-73,
+// /root/reference/src/resnet.jl:11-32.  See DESIGN.md "Network kernels".
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "agz_common.h"
+
+namespace agz {
+
+constexpr int kC = 256;        // tower width, neural_net.jl:16
+constexpr int kCinStem = 17;   // 2*planes + 1, neural_net.jl:19
+constexpr int kCinStemPad = 32;
+
+struct ConvHost {
+  int k = 3, cin = 0, cout = 0;
+  std::vector<float> w, b, beta, gamma, mean, var;
+  float eps = 1e-5f;
+};
+struct DenseHost {
+  int in = 0, out = 0;
+  std::vector<float> w, b;
+};
+
+class Net {
+ public:
+  Net(int N, int tower, hipStream_t stream);
+  int N() const { return N_; }
+  int P() const { return P_; }
+  int A() const { return A_; }
+  int tower() const { return tower_; }
+
+  int64_t param_count(int layer, int kind) const;
+  void set(int layer, int kind, const float* data, int64_t count);
+  void init_synthetic(uint64_t seed);
+
+  // Reserve activation workspace for up to `bcap` positions.
+  void reserve(int bcap);
+  // d_x32: [bcap*P][32] stem input (17 planes + zero pad) ; d_count: device int, number of
+  // positions actually present (<= bcap); outputs d_pi [bcap][A] (row per position), d_v.
+  void forward(const float* d_x32, const int* d_count, int bcap, float* d_pi, float* d_v);
+  // one tower conv launch on resident synthetic activations (for roofline timing)
+  void launch_tower_conv_once(const int* d_count, int bcap);
+
+  double flops_per_eval() const;         // BASELINE.md F_eval
+  double conv_flops_per_launch(int B) const { return 2.0 * B * P_ * 9.0 * kC * kC; }
+
+ private:
+  void pack();
+  ConvHost* conv(int layer);
+  const ConvHost* conv(int layer) const;
+  DenseHost* dense(int layer);
+  const DenseHost* dense(int layer) const;
+
+  int N_, P_, A_, tower_;
+  hipStream_t stream_;
+  ConvHost stem_, vconv_, pconv_;
+  std::vector<ConvHost> tconv_;
+  DenseHost vfc1_, vfc2_, pfc_;
+  bool dirty_ = true;
+
+  // device-resident packed parameters
+  DevBuf<float> d_wstem_, d_wtower_;      // [cout][9*cin_pad] per layer
+  DevBuf<float> d_scale_, d_shift_;       // (1 + 2*tower) x 256
+  DevBuf<float> d_head_;                  // head conv weights + affine
+  DevBuf<float> d_vfc1w_, d_vfc1b_, d_vfc2w_, d_vfc2b_, d_pfcw_, d_pfcb_;
+  // workspace
+  int bcap_ = 0;
+  DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
+};
+
+// feature extraction entry points (features.jl:3-26) from the reference's own position format
+void launch_features_from_deltas(const int8_t* d_boards, const int8_t* d_deltas, const int32_t* d_ndeltas,
+                                 const int8_t* d_to_play, int B, int N, float* d_x32, float* d_whcn,
+                                 hipStream_t stream);
+// WHCN feature tensor -> stem input layout
+void launch_whcn_to_x32(const float* d_whcn, int B, int N, float* d_x32, hipStream_t stream);
+
+}  // namespace agz

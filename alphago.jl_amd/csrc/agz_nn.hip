@@ -1,0 +1,565 @@
+// agz_nn.hip -- hand-written gfx950 kernels for the AlphaGo.jl policy/value network.
+//
+//   k_conv3x3_mfma   3x3 convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32 with the
+//                    bias + inference-BatchNorm affine, residual add and ReLU fused into the
+//                    epilogue (neural_net.jl:19-21, resnet.jl:26-32).  Exact-f32 MFMA: the
+//                    north_star asks for 1e-4 agreement with the fp32/fp64 Flux CPU path.
+//   k_head_conv      the two 1x1 head convolutions (256->1, 256->2) + BN + ReLU, one wavefront
+//                    per board point with a DPP/shuffle reduction (neural_net.jl:23,28).
+//   k_head_fc        Dense(2N^2->A)+softmax and Dense(N^2->256,relu)+Dense(256->1,tanh),
+//                    one workgroup per position (neural_net.jl:24-26,29-30).
+//   k_feats_*        board-plane feature extraction (features.jl:3-26).
+//
+// GEMM view of a tower conv: M = B*N^2 rows (positions x points, row = b*P + p,
+// p = row + N*col), N = 256 output channels, K = 9*256 ordered (tap, cin).  Activations are
+// [M][256] f32 (channel fastest) so that an A-tile row is one 128-byte line per 32-channel
+// chunk; weights are pre-packed once to Wt[cout][tap][cin] with the true-convolution kernel
+// flip of NNlib applied at pack time, so the B-tile has the same shape as the A-tile.
+#include "agz_nn.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "../../include/agz_draws.h"
+
+namespace agz {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ conv3x3 implicit GEMM
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_STRIDE = BK + 4;   // 36 floats: r*36 mod 64 hits 16 distinct 16-B slots for
+                                     // the 16 rows of every ds_read_b128 lane group
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(
+    const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+    const int* __restrict__ d_count, int N, int relu) {
+  constexpr int NCHUNK = 9 * CIN / BK;
+  constexpr int CPT = CIN / BK;  // chunks per tap
+  __shared__ __attribute__((aligned(16))) float lds[2][2][BM * LDS_STRIDE];
+
+  const int P = N * N;
+  const long M = (long)(*d_count) * P;
+
+  // XCD-aware, bijective remap: consecutive logical tiles (which share the A rows / halo)
+  // run on the same XCD and therefore hit the same L2.
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const long m0 = (long)(swz >> 1) * BM;
+  const int n0 = (swz & 1) * BN;
+  if (m0 >= M) return;
+
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 3, c4 = tid & 7;
+
+  // per-thread staging rows (4 rows of the A tile, 4 rows of the B tile); everything is kept
+  // in named scalars so that nothing is ever indexed dynamically (no scratch).
+#define AGZ_ROWSETUP(i)                                            \
+  const long mrow##i = m0 + lrow + 32 * i;                         \
+  const bool rvalid##i = mrow##i < M;                              \
+  const int p##i = (int)(mrow##i % P);                             \
+  const int ri##i = p##i % N, cj##i = p##i / N;                    \
+  const float* wrow##i = wt + (long)(n0 + lrow + 32 * i) * (9 * CIN) + c4 * 4;
+  AGZ_ROWSETUP(0) AGZ_ROWSETUP(1) AGZ_ROWSETUP(2) AGZ_ROWSETUP(3)
+#undef AGZ_ROWSETUP
+
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define AGZ_LOADROW(i, da, db, aoff, boff)                                                             \
+  {                                                                                                     \
+    const bool ok = rvalid##i && (unsigned)(ri##i + da) < (unsigned)N && (unsigned)(cj##i + db) < (unsigned)N; \
+    ra##i = ok ? *reinterpret_cast<const float4*>(x + (mrow##i + da + N * db) * CIN + aoff)             \
+               : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+    rb##i = *reinterpret_cast<const float4*>(wrow##i + boff);                                           \
+  }
+#define AGZ_LOAD_CHUNK(c)                                         \
+  {                                                               \
+    const int tap_ = (c) / CPT, ci0_ = ((c) % CPT) * BK;          \
+    const int da_ = tap_ % 3 - 1, db_ = tap_ / 3 - 1;             \
+    const int aoff_ = ci0_ + c4 * 4, boff_ = (c) * BK;            \
+    AGZ_LOADROW(0, da_, db_, aoff_, boff_)                        \
+    AGZ_LOADROW(1, da_, db_, aoff_, boff_)                        \
+    AGZ_LOADROW(2, da_, db_, aoff_, boff_)                        \
+    AGZ_LOADROW(3, da_, db_, aoff_, boff_)                        \
+  }
+#define AGZ_STOREROW(buf, i)                                                                           \
+  *reinterpret_cast<float4*>(&lds[buf][0][(lrow + 32 * i) * LDS_STRIDE + c4 * 4]) = ra##i;             \
+  *reinterpret_cast<float4*>(&lds[buf][1][(lrow + 32 * i) * LDS_STRIDE + c4 * 4]) = rb##i;
+#define AGZ_STORE_CHUNK(buf) { AGZ_STOREROW(buf, 0) AGZ_STOREROW(buf, 1) AGZ_STOREROW(buf, 2) AGZ_STOREROW(buf, 3) }
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  AGZ_LOAD_CHUNK(0)
+  AGZ_STORE_CHUNK(0)
+  __syncthreads();
+
+  for (int c = 0; c < NCHUNK; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < NCHUNK) AGZ_LOAD_CHUNK(c + 1)   // global loads fly under the MFMAs below
+    const float* As = &lds[buf][0][(wr * 64 + l31) * LDS_STRIDE + hi * 4];
+    const float* Bs = &lds[buf][1][(wc * 64 + l31) * LDS_STRIDE + hi * 4];
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      // K is consumed in a permuted order (lanes 0-31 take k = 8kk+s, lanes 32-63 take
+      // k = 8kk+4+s): the reduction is order-free and both operands use the same map, which
+      // lets every lane fetch its four k-steps with one ds_read_b128.
+      const float4 a0 = *reinterpret_cast<const float4*>(As + kk * 8);
+      const float4 a1 = *reinterpret_cast<const float4*>(As + 32 * LDS_STRIDE + kk * 8);
+      const float4 b0 = *reinterpret_cast<const float4*>(Bs + kk * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(Bs + 32 * LDS_STRIDE + kk * 8);
+#define AGZ_MFMA4(f)                                                                          \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.f, b0.f, acc[0][0], 0, 0, 0);             \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.f, b1.f, acc[0][1], 0, 0, 0);             \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.f, b0.f, acc[1][0], 0, 0, 0);             \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.f, b1.f, acc[1][1], 0, 0, 0);
+      AGZ_MFMA4(x) AGZ_MFMA4(y) AGZ_MFMA4(z) AGZ_MFMA4(w)
+#undef AGZ_MFMA4
+    }
+    if (c + 1 < NCHUNK) AGZ_STORE_CHUNK(buf ^ 1)
+    __syncthreads();
+  }
+
+#undef AGZ_LOADROW
+#undef AGZ_LOAD_CHUNK
+#undef AGZ_STOREROW
+#undef AGZ_STORE_CHUNK
+  // epilogue: y = act(scale*acc + shift (+ residual)); C/D map of the 32x32 MFMA:
+  // col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int n = n0 + wc * 64 + tn * 32 + l31;
+    const float sc = scale[n], sh = shift[n];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long m = m0 + wr * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (m < M) {
+          float v = acc[tm][tn][e] * sc + sh;
+          if (res) v += res[m * kC + n];
+          if (relu) v = fmaxf(v, 0.f);
+          y[m * kC + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ heads
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// hp: wv[256] | wp0[256] | wp1[256] | sv tv sp0 tp0 sp1 tp1
+__global__ __launch_bounds__(256) void k_head_conv(const float* __restrict__ x, const float* __restrict__ hp,
+                                                    float* __restrict__ vh, float* __restrict__ ph,
+                                                    const int* __restrict__ d_count, int P) {
+  const long M = (long)(*d_count) * P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4 wv = *reinterpret_cast<const float4*>(hp + lane * 4);
+  const float4 w0 = *reinterpret_cast<const float4*>(hp + 256 + lane * 4);
+  const float4 w1 = *reinterpret_cast<const float4*>(hp + 512 + lane * 4);
+  const float sv = hp[768], tv = hp[769], s0 = hp[770], t0 = hp[771], s1 = hp[772], t1 = hp[773];
+  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + m * kC + lane * 4);
+    float dv = xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+    float d0 = xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
+    float d1 = xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
+    dv = wave_sum(dv);
+    d0 = wave_sum(d0);
+    d1 = wave_sum(d1);
+    if (lane == 0) {
+      vh[m] = fmaxf(dv * sv + tv, 0.f);
+      ph[m * 2 + 0] = fmaxf(d0 * s0 + t0, 0.f);
+      ph[m * 2 + 1] = fmaxf(d1 * s1 + t1, 0.f);
+    }
+  }
+}
+
+__device__ float block_reduce(float v, bool is_max, float* red /*[4]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(v, o, 64);
+    v = is_max ? fmaxf(v, t) : v + t;
+  }
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_head_fc(
+    const float* __restrict__ vh, const float* __restrict__ ph, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    const float* __restrict__ wp, const float* __restrict__ bp, float* __restrict__ pi,
+    float* __restrict__ v, const int* __restrict__ d_count, int P, int A) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* vin = sm;             // [P]
+  float* pin = sm + P;         // [2P]  index p + P*c (Julia reshape of W x H x C)
+  float* logit = pin + 2 * P;  // [A]
+  float* red = logit + A;      // [4]
+  const int b = blockIdx.x;
+  if (b >= *d_count) return;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < P; i += 256) {
+    vin[i] = vh[(long)b * P + i];
+    pin[i] = ph[((long)b * P + i) * 2 + 0];
+    pin[P + i] = ph[((long)b * P + i) * 2 + 1];
+  }
+  __syncthreads();
+  // policy logits: Dense(2P -> A), W [out,in] column-major
+  float lmax = -INFINITY;
+  for (int o = tid; o < A; o += 256) {
+    float z = bp[o];
+    for (int i = 0; i < 2 * P; ++i) z += wp[o + (long)A * i] * pin[i];
+    logit[o] = z;
+    lmax = fmaxf(lmax, z);
+  }
+  const float mx = block_reduce(lmax, true, red);
+  float lsum = 0.f;
+  for (int o = tid; o < A; o += 256) {
+    const float e = expf(logit[o] - mx);
+    logit[o] = e;
+    lsum += e;
+  }
+  const float sum = block_reduce(lsum, false, red);
+  for (int o = tid; o < A; o += 256) pi[(long)b * A + o] = logit[o] / sum;
+  // value: Dense(P -> 256, relu) -> Dense(256 -> 1, tanh)
+  float h = b1[tid];
+  for (int i = 0; i < P; ++i) h += w1[tid + 256 * i] * vin[i];
+  h = fmaxf(h, 0.f);
+  const float s = block_reduce(h * w2[tid], false, red);
+  if (tid == 0) v[b] = tanhf(s + b2[0]);
+}
+
+// ------------------------------------------------------------------ features
+
+// One workgroup per position; threads stride over the board.  The eight history boards are
+// rebuilt exactly as stone_features does (features.jl:8-14): B_k = B_{k-1} - delta_{k-1}
+// while deltas last, then the oldest board is repeated.
+__global__ __launch_bounds__(128) void k_feats_from_deltas(
+    const int8_t* __restrict__ boards, const int8_t* __restrict__ deltas, const int32_t* __restrict__ ndeltas,
+    const int8_t* __restrict__ to_play, int B, int N, float* __restrict__ x32, float* __restrict__ whcn) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int P = N * N;
+  const int nd = ndeltas[b];
+  const int tp = to_play[b];
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    int cur = boards[(long)b * P + p];
+    float f[32];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k >= 1 && k <= nd) cur -= deltas[((long)b * 7 + (k - 1)) * P + p];
+      f[2 * k] = cur == tp ? 1.f : 0.f;
+      f[2 * k + 1] = cur == -tp ? 1.f : 0.f;
+    }
+    f[16] = (float)tp;   // colour plane is +1 / -1, features.jl:22
+#pragma unroll
+    for (int c = 17; c < 32; ++c) f[c] = 0.f;
+    if (x32) {
+      float4* dst = reinterpret_cast<float4*>(x32 + ((long)b * P + p) * 32);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) dst[c] = make_float4(f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]);
+    }
+    if (whcn) {
+#pragma unroll
+      for (int c = 0; c < 17; ++c) whcn[(long)P * (c + 17L * b) + p] = f[c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void k_whcn_to_x32(const float* __restrict__ whcn, int B, int P,
+                                                      float* __restrict__ x32) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float* dst = x32 + ((long)b * P + p) * 32;
+    for (int c = 0; c < 17; ++c) dst[c] = whcn[(long)P * (c + 17L * b) + p];
+    for (int c = 17; c < 32; ++c) dst[c] = 0.f;
+  }
+}
+
+void launch_features_from_deltas(const int8_t* d_boards, const int8_t* d_deltas, const int32_t* d_ndeltas,
+                                 const int8_t* d_to_play, int B, int N, float* d_x32, float* d_whcn,
+                                 hipStream_t stream) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_feats_from_deltas, dim3(B), dim3(128), 0, stream, d_boards, d_deltas, d_ndeltas,
+                     d_to_play, B, N, d_x32, d_whcn);
+  AGZ_HIP(hipGetLastError());
+}
+
+void launch_whcn_to_x32(const float* d_whcn, int B, int N, float* d_x32, hipStream_t stream) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_whcn_to_x32, dim3(B), dim3(128), 0, stream, d_whcn, B, N * N, d_x32);
+  AGZ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ host side
+
+static void conv_init(ConvHost& c, int k, int cin, int cout) {
+  c.k = k; c.cin = cin; c.cout = cout;
+  c.w.assign((size_t)k * k * cin * cout, 0.f);
+  c.b.assign(cout, 0.f);
+  c.beta.assign(cout, 0.f);
+  c.gamma.assign(cout, 1.f);
+  c.mean.assign(cout, 0.f);
+  c.var.assign(cout, 1.f);
+  c.eps = 1e-5f;
+}
+static void dense_init(DenseHost& d, int in, int out) {
+  d.in = in; d.out = out;
+  d.w.assign((size_t)in * out, 0.f);
+  d.b.assign(out, 0.f);
+}
+
+Net::Net(int N, int tower, hipStream_t stream) : N_(N), P_(N * N), A_(N * N + 1), tower_(tower), stream_(stream) {
+  conv_init(stem_, 3, kCinStem, kC);
+  tconv_.resize(2 * tower);
+  for (auto& c : tconv_) conv_init(c, 3, kC, kC);
+  conv_init(vconv_, 1, kC, 1);
+  conv_init(pconv_, 1, kC, 2);
+  dense_init(vfc1_, P_, 256);
+  dense_init(vfc2_, 256, 1);
+  dense_init(pfc_, 2 * P_, A_);
+}
+
+ConvHost* Net::conv(int layer) {
+  if (layer == 0) return &stem_;
+  if (layer >= 1 && layer <= 2 * tower_) return &tconv_[layer - 1];
+  if (layer == AGZ_L_VALUE_CONV) return &vconv_;
+  if (layer == AGZ_L_POLICY_CONV) return &pconv_;
+  return nullptr;
+}
+const ConvHost* Net::conv(int layer) const { return const_cast<Net*>(this)->conv(layer); }
+DenseHost* Net::dense(int layer) {
+  if (layer == AGZ_L_VALUE_FC1) return &vfc1_;
+  if (layer == AGZ_L_VALUE_FC2) return &vfc2_;
+  if (layer == AGZ_L_POLICY_FC) return &pfc_;
+  return nullptr;
+}
+const DenseHost* Net::dense(int layer) const { return const_cast<Net*>(this)->dense(layer); }
+
+static std::vector<float>* conv_field(ConvHost* c, int kind) {
+  switch (kind) {
+    case AGZ_K_WEIGHT: return &c->w;
+    case AGZ_K_BIAS: return &c->b;
+    case AGZ_K_BN_BETA: return &c->beta;
+    case AGZ_K_BN_GAMMA: return &c->gamma;
+    case AGZ_K_BN_MEAN: return &c->mean;
+    case AGZ_K_BN_VAR: return &c->var;
+    default: return nullptr;
+  }
+}
+
+int64_t Net::param_count(int layer, int kind) const {
+  if (const ConvHost* c = conv(layer)) {
+    if (kind == AGZ_K_BN_EPS) return 1;
+    auto* f = conv_field(const_cast<ConvHost*>(c), kind);
+    return f ? (int64_t)f->size() : -1;
+  }
+  if (const DenseHost* d = dense(layer)) {
+    if (kind == AGZ_K_WEIGHT) return (int64_t)d->w.size();
+    if (kind == AGZ_K_BIAS) return (int64_t)d->b.size();
+  }
+  return -1;
+}
+
+void Net::set(int layer, int kind, const float* data, int64_t count) {
+  AGZ_REQUIRE(data != nullptr, AGZ_BAD_ARGUMENT, "agz_net_set_weights: null data");
+  const int64_t want = param_count(layer, kind);
+  AGZ_REQUIRE(want >= 0, AGZ_BAD_ARGUMENT, "agz_net_set_weights: no parameter (layer %d, kind %d)", layer, kind);
+  AGZ_REQUIRE(want == count, AGZ_BAD_SHAPE, "agz_net_set_weights: layer %d kind %d expects %lld floats, got %lld",
+              layer, kind, (long long)want, (long long)count);
+  if (ConvHost* c = conv(layer)) {
+    if (kind == AGZ_K_BN_EPS) c->eps = data[0];
+    else std::memcpy(conv_field(c, kind)->data(), data, sizeof(float) * (size_t)count);
+  } else {
+    DenseHost* d = dense(layer);
+    std::memcpy((kind == AGZ_K_WEIGHT ? d->w : d->b).data(), data, sizeof(float) * (size_t)count);
+  }
+  dirty_ = true;
+}
+
+// glorot_uniform over nfan (Flux utils): limit = sqrt(6/(fan_in+fan_out)); the element stream
+// is the AGZ_SITE_WEIGHTS site of the draw header, so any consumer of that header (the test
+// oracle included) generates the same tensors from the same seed.
+static void glorot(std::vector<float>& w, double fan_in, double fan_out, uint64_t seed, int layer) {
+  const double limit = std::sqrt(6.0 / (fan_in + fan_out));
+  const uint64_t key = (uint64_t)(int64_t)(layer + 4096);
+  for (size_t i = 0; i < w.size(); ++i) {
+    const double u = agz_u01(agz_draw_u64(seed, key, 0, AGZ_SITE_WEIGHTS, (uint64_t)i));
+    w[i] = (float)((2.0 * u - 1.0) * limit);
+  }
+}
+
+void Net::init_synthetic(uint64_t seed) {
+  for (int l = 0; l <= 2 * tower_; ++l) {
+    ConvHost* c = conv(l);
+    const int cin = c->cin, cout = c->cout, k = c->k;
+    conv_init(*c, k, cin, cout);
+    glorot(c->w, 9.0 * cin, 9.0 * cout, seed, l);
+  }
+  conv_init(vconv_, 1, kC, 1);
+  conv_init(pconv_, 1, kC, 2);
+  glorot(vconv_.w, kC, 1, seed, AGZ_L_VALUE_CONV);
+  glorot(pconv_.w, kC, 2, seed, AGZ_L_POLICY_CONV);
+  dense_init(vfc1_, P_, 256);
+  dense_init(vfc2_, 256, 1);
+  dense_init(pfc_, 2 * P_, A_);
+  glorot(vfc1_.w, vfc1_.in, vfc1_.out, seed, AGZ_L_VALUE_FC1);
+  glorot(vfc2_.w, vfc2_.in, vfc2_.out, seed, AGZ_L_VALUE_FC2);
+  glorot(pfc_.w, pfc_.in, pfc_.out, seed, AGZ_L_POLICY_FC);
+  dirty_ = true;
+}
+
+// Flux [kw,kh,cin,cout] column-major -> Wt[cout][tap][cin_pad].  NNlib's conv is a TRUE
+// convolution: Flux index (a,b) multiplies x[i + 1 - a, j + 1 - b], i.e. tap offset
+// (da,db) = (1-a, 1-b); tap = (da+1) + 3*(db+1).
+static void pack_conv3(const ConvHost& c, int cin_pad, float* out) {
+  const int cin = c.cin, cout = c.cout;
+  std::memset(out, 0, sizeof(float) * (size_t)cout * 9 * cin_pad);
+  for (int o = 0; o < cout; ++o)
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        const int tap = (2 - a) + 3 * (2 - b);
+        for (int ci = 0; ci < cin; ++ci)
+          out[((size_t)o * 9 + tap) * cin_pad + ci] = c.w[a + 3 * (b + 3 * (ci + (size_t)cin * o))];
+      }
+}
+
+static void bn_affine(const ConvHost& c, float* scale, float* shift) {
+  for (int o = 0; o < c.cout; ++o) {
+    const double s = (double)c.gamma[o] / std::sqrt((double)c.var[o] + (double)c.eps);
+    scale[o] = (float)s;
+    shift[o] = (float)((double)c.beta[o] + s * ((double)c.b[o] - (double)c.mean[o]));
+  }
+}
+
+void Net::pack() {
+  if (!dirty_) return;
+  const int L = 1 + 2 * tower_;
+  std::vector<float> scale((size_t)L * kC), shift((size_t)L * kC);
+  {
+    std::vector<float> w((size_t)kC * 9 * kCinStemPad);
+    pack_conv3(stem_, kCinStemPad, w.data());
+    d_wstem_.ensure(w.size());
+    AGZ_HIP(hipMemcpyAsync(d_wstem_.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
+    bn_affine(stem_, scale.data(), shift.data());
+  }
+  if (tower_ > 0) {
+    const size_t per = (size_t)kC * 9 * kC;
+    std::vector<float> w(per * 2 * tower_);
+    for (int l = 0; l < 2 * tower_; ++l) {
+      pack_conv3(tconv_[l], kC, w.data() + per * l);
+      bn_affine(tconv_[l], scale.data() + (size_t)(l + 1) * kC, shift.data() + (size_t)(l + 1) * kC);
+    }
+    d_wtower_.ensure(w.size());
+    AGZ_HIP(hipMemcpyAsync(d_wtower_.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
+  }
+  auto up = [&](DevBuf<float>& d, const std::vector<float>& h) {
+    d.ensure(h.size());
+    AGZ_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
+  };
+  up(d_scale_, scale);
+  up(d_shift_, shift);
+  std::vector<float> hp(776, 0.f);
+  for (int c = 0; c < kC; ++c) {
+    hp[c] = vconv_.w[c];                       // [1,1,cin,1]
+    hp[256 + c] = pconv_.w[c];                 // [1,1,cin,2] column-major: ci + cin*o
+    hp[512 + c] = pconv_.w[kC + c];
+  }
+  float s[2], t[2];
+  bn_affine(vconv_, s, t);
+  hp[768] = s[0]; hp[769] = t[0];
+  bn_affine(pconv_, s, t);
+  hp[770] = s[0]; hp[771] = t[0]; hp[772] = s[1]; hp[773] = t[1];
+  up(d_head_, hp);
+  up(d_vfc1w_, vfc1_.w); up(d_vfc1b_, vfc1_.b);
+  up(d_vfc2w_, vfc2_.w); up(d_vfc2b_, vfc2_.b);
+  up(d_pfcw_, pfc_.w); up(d_pfcb_, pfc_.b);
+  dirty_ = false;
+}
+
+void Net::reserve(int bcap) {
+  if (bcap <= bcap_) return;
+  const size_t rows = (size_t)bcap * P_;
+  d_a_.alloc(rows * kC);
+  d_b_.alloc(rows * kC);
+  d_t_.alloc(rows * kC);
+  d_vh_.alloc(rows);
+  d_ph_.alloc(rows * 2);
+  bcap_ = bcap;
+}
+
+static inline int conv_grid(int bcap, int P) { return ceil_div((long)bcap * P, BM) * (kC / BN); }
+
+void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi, float* d_v) {
+  pack();
+  reserve(bcap);
+  const int grid = conv_grid(bcap, P_);
+  float *a = d_a_.p, *b = d_b_.p, *t = d_t_.p;
+  hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad>), dim3(grid), dim3(256), 0, stream_, d_x32, d_wstem_.p,
+                     d_scale_.p, d_shift_.p, (const float*)nullptr, a, d_count, N_, 1);
+  const size_t per = (size_t)kC * 9 * kC;
+  for (int blk = 0; blk < tower_; ++blk) {
+    const int l1 = 2 * blk, l2 = 2 * blk + 1;
+    hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)a,
+                       d_wtower_.p + per * l1, d_scale_.p + (size_t)(l1 + 1) * kC,
+                       d_shift_.p + (size_t)(l1 + 1) * kC, (const float*)nullptr, t, d_count, N_, 1);
+    hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)t,
+                       d_wtower_.p + per * l2, d_scale_.p + (size_t)(l2 + 1) * kC,
+                       d_shift_.p + (size_t)(l2 + 1) * kC, (const float*)a, b, d_count, N_, 1);
+    std::swap(a, b);
+  }
+  const int hgrid = std::min(ceil_div((long)bcap * P_, 4), 256 * 16);
+  hipLaunchKernelGGL(k_head_conv, dim3(hgrid), dim3(256), 0, stream_, (const float*)a, d_head_.p, d_vh_.p,
+                     d_ph_.p, d_count, P_);
+  const size_t smem = sizeof(float) * (size_t)(3 * P_ + A_ + 4);
+  hipLaunchKernelGGL(k_head_fc, dim3(bcap), dim3(256), smem, stream_, (const float*)d_vh_.p,
+                     (const float*)d_ph_.p, d_vfc1w_.p, d_vfc1b_.p, d_vfc2w_.p, d_vfc2b_.p, d_pfcw_.p,
+                     d_pfcb_.p, d_pi, d_v, d_count, P_, A_);
+  AGZ_HIP(hipGetLastError());
+}
+
+void Net::launch_tower_conv_once(const int* d_count, int bcap) {
+  pack();
+  reserve(bcap);
+  AGZ_REQUIRE(tower_ > 0, AGZ_BAD_ARGUMENT, "no tower conv in a tower_height=0 network");
+  const int grid = conv_grid(bcap, P_);
+  hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)d_a_.p,
+                     d_wtower_.p, d_scale_.p + kC, d_shift_.p + kC, (const float*)nullptr, d_t_.p, d_count, N_, 1);
+  AGZ_HIP(hipGetLastError());
+}
+
+double Net::flops_per_eval() const {
+  // F_eval(N,t)
+  const double P = P_;
+  return 2.0 * P * (9.0 * 17 * 256 + tower_ * 2.0 * 9 * 256 * 256) + 2.0 * P * 256 * 3 +
+         2.0 * (2.0 * P * (P + 1) + P * 256 + 256);
+}
+
+}  // namespace agz

@@ -1,0 +1,247 @@
+/*
+ * agz.h -- C ABI of libagz.so, the MI355X-native self-play engine for AlphaGo.jl's hot path.
+ *
+ * The reference has no FFI of its own: its boundary is the Julia call surface that
+ * train()/evaluate()/play() and the test-suite use.  Each entry point below
+ * names the reference interface it stands in for (file:line under /root/reference); the thin
+ * Julia `ccall` wrapper a maintainer would add is alphago.jl_amd/julia/AlphaGoMI.jl and the
+ * binding recipe is INTEGRATION.md.  Everything is extern "C", plain pointers and sizes.
+ *
+ * Conventions
+ *   - all indices are 0-based: board point p = row + N*col (Julia's column-major linear index
+ *     minus one, src/game/go/coords.jl:6-7); action a in [0, A), A = N*N + 1, a == N*N = pass.
+ *   - colours: BLACK = +1, WHITE = -1, EMPTY = 0 (src/game/go/board.jl:12).
+ *   - tensors cross in the layouts Flux stores them: conv [kw,kh,cin,cout] column-major,
+ *     dense [out,in] column-major, features N x N x 17 x B (WHCN), pi A x B, v B.
+ *   - every function returns an agz_status (0 = OK); agz_last_error() describes the last
+ *     failure of that engine.  Pointers are HOST pointers unless the name says _device.
+ *   - an engine handle is bound to one HIP device and is not thread-safe (the reference is
+ *     single-threaded with mutable module globals, src/mcts.jl:11-13).
+ *   - the engine fails loudly (AGZ_HIP_ERROR) when no gfx950 device is present; there is no
+ *     CPU fallback anywhere behind this ABI.
+ */
+#ifndef AGZ_H
+#define AGZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGZ_VERSION 100
+
+typedef int32_t agz_status;
+#define AGZ_OK 0
+#define AGZ_ILLEGAL_MOVE 1        /* IllegalMove   src/AlphaGo.jl:8, board.jl:265,470        */
+#define AGZ_ASSERT_DONE_NODE 2    /* AssertionError src/mcts.jl:196                          */
+#define AGZ_HISTORY_INCOMPLETE 3  /* AssertionError board.jl:568, mcts_play.jl:127           */
+#define AGZ_BAD_SHAPE 4           /* AssertionError src/mcts.jl:190                          */
+#define AGZ_ASSERT_SOFTPICK 5     /* AssertionError src/mcts_play.jl:67                      */
+#define AGZ_BAD_ARGUMENT 6
+#define AGZ_HIP_ERROR 7
+#define AGZ_POOL_EXHAUSTED 8      /* a game's node pool overflowed (ours; no reference analogue) */
+#define AGZ_RCCL_ERROR 9
+#define AGZ_NOT_READY 10
+
+typedef struct agz_engine agz_engine;
+
+/* One POD for every knob of the hot path (SURVEY.md section 5 "Config / flags"):
+ * GoEnv(board_size) go.jl:10; NeuralNet(env; tower_height) neural_net.jl:13;
+ * MCTSPlayer(env, net; num_readouts, two_player_mode, resign_threshold) mcts_play.jl:17-18;
+ * tree_search!(player, parallel_readouts) mcts_play.jl:73; komi board.jl:297;
+ * c_puct / dirichlet_noise_weight mcts.jl:11-13. */
+typedef struct {
+  int32_t board_size;              /* N; 19 */
+  int32_t tower_height;            /* residual blocks; 19 */
+  int32_t games;                   /* concurrent game slots on this GPU */
+  int32_t num_readouts;            /* 800 */
+  int32_t parallel_readouts;       /* 8 */
+  int32_t two_player_mode;         /* 0 */
+  float komi;                      /* 7.5 */
+  float reserved0;
+  double c_puct;                   /* 0.96 */
+  double dirichlet_noise_weight;   /* 0.25 */
+  double resign_threshold;         /* -0.9 */
+  double resign_disable_fraction;  /* 0.05, selfplay.jl:9 */
+  uint64_t seed;                   /* draw-stream seed (include/agz_draws.h) */
+  uint64_t game_id_base;           /* first global game id played by this engine */
+  uint64_t game_id_stride;         /* id increment when a slot is recycled (= total slots) */
+  int32_t max_nodes_per_game;      /* 0 = auto (16*num_readouts + 256) */
+  int32_t device;                  /* HIP device ordinal */
+  int32_t external_network;        /* 1: pi/v are supplied by the caller (duck-typed network) */
+  int32_t stagger_moves;           /* bench only: random opening prefix of up to this many moves */
+  int32_t record_capacity_games;   /* finished-game record slots kept on the device; 0 = auto */
+  int32_t reserved1;
+} agz_config;
+
+int32_t agz_version(void);
+void agz_config_default(agz_config* cfg);
+agz_status agz_engine_create(const agz_config* cfg, agz_engine** out);
+void agz_engine_destroy(agz_engine* e);
+const char* agz_last_error(const agz_engine* e);   /* e may be NULL: last create() failure */
+agz_status agz_engine_sync(agz_engine* e);
+
+/* ---------------------------------------------------------------- network ------------- */
+/* NeuralNet(env; tower_height), neural_net.jl:13-33.  layer ids: 0 = stem conv+BN;
+ * 1..2*tower = tower convs (block b, conv c -> 1 + 2b + c); negative = heads. */
+#define AGZ_L_VALUE_CONV (-1)
+#define AGZ_L_POLICY_CONV (-2)
+#define AGZ_L_VALUE_FC1 (-3)
+#define AGZ_L_VALUE_FC2 (-4)
+#define AGZ_L_POLICY_FC (-5)
+#define AGZ_K_WEIGHT 0
+#define AGZ_K_BIAS 1
+#define AGZ_K_BN_BETA 2
+#define AGZ_K_BN_GAMMA 3
+#define AGZ_K_BN_MEAN 4
+#define AGZ_K_BN_VAR 5
+#define AGZ_K_BN_EPS 6
+/* copies `count` floats (caller keeps ownership); Flux layouts, kernel flip done inside */
+agz_status agz_net_set_weights(agz_engine* e, int32_t layer, int32_t kind, const float* data,
+                               int64_t count);
+int64_t agz_net_param_count(const agz_engine* e, int32_t layer, int32_t kind);
+/* Flux-default-equivalent init from the draw stream (glorot-uniform, zero bias, BN identity,
+ * eps 1e-5) -- the synthetic weights of SURVEY.md 8d */
+agz_status agz_net_init_synthetic(agz_engine* e, uint64_t seed);
+/* (nn)(positions::Vector{Position}) -> (pi A x B, v B), neural_net.jl:57-68.
+ * Position SoA: boards int8[B][N*N]; deltas int8[B][7][N*N] newest first; ndeltas int32[B];
+ * to_play int8[B]. */
+agz_status agz_net_forward(agz_engine* e, const int8_t* boards, const int8_t* deltas,
+                           const int32_t* ndeltas, const int8_t* to_play, int32_t B,
+                           float* pi_out, float* v_out);
+/* same on a feature tensor N x N x 17 x B already in host memory */
+agz_status agz_net_forward_features(agz_engine* e, const float* feats, int32_t B, float* pi_out,
+                                    float* v_out);
+/* get_feats(pos) -> N x N x 17 (x B), features.jl:3-26 */
+agz_status agz_features(agz_engine* e, const int8_t* boards, const int8_t* deltas,
+                        const int32_t* ndeltas, const int8_t* to_play, int32_t B, float* out);
+/* micro-benchmark hook: run the network `iters` times on B resident synthetic positions and
+ * return the average milliseconds per forward (HIP events on the engine's stream) */
+agz_status agz_net_time_forward(agz_engine* e, int32_t B, int32_t iters, float* ms_out);
+/* average duration (ms) of the dominant 3x3 256->256 conv launch over the same kind of run */
+agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_out);
+
+/* ---------------------------------------------------------------- Go rules (batched) --- */
+/* play_move!(pos, c), board.jl:451-509 / pass_move! :426-440.  In/out SoA per position:
+ * boards int8[B][N*N], to_play int8[B], ko int32[B] (-1 = none), moves int32[B].
+ * status_out[b] = AGZ_OK or AGZ_ILLEGAL_MOVE (then the outputs for b repeat the input). */
+agz_status agz_go_play(agz_engine* e, const int8_t* boards, const int8_t* to_play, const int32_t* ko,
+                       const int32_t* moves, int32_t B, int8_t* boards_out, int32_t* ko_out,
+                       int32_t* ncaptured_out, int32_t* status_out);
+/* all_legal_moves(pos) -> Int8[A], board.jl:393-424 */
+agz_status agz_go_legal(agz_engine* e, const int8_t* boards, const int8_t* to_play, const int32_t* ko,
+                        int32_t B, int8_t* legal_out /* [B][A] */);
+/* score(pos) board.jl:511-533 (area - komi, Black-positive) */
+agz_status agz_go_score(agz_engine* e, const int8_t* boards, const float* komi, int32_t B,
+                        float* score_out);
+
+/* ---------------------------------------------------------------- batched self-play ----- */
+/* selfplay(env, nn, num_ro) selfplay.jl:1-45, many games at once.  Start (re)initialises
+ * every slot; each step is one tree_search! (mcts_play.jl:73-98) for every live game plus the
+ * per-move phase for games whose readout budget is spent; finished games are recorded and
+ * their slot recycled until `total_games` have been started (0 = recycle forever). */
+agz_status agz_selfplay_start(agz_engine* e, int64_t total_games);
+agz_status agz_selfplay_step(agz_engine* e, int32_t nsteps);          /* asynchronous */
+typedef struct {
+  int64_t steps;               /* tree_search! rounds executed                          */
+  int64_t positions;           /* self-play moves played (= searches_pi entries)        */
+  int64_t games_started;
+  int64_t games_finished;
+  int64_t evals;               /* network evaluations (leaves sent to the NN)            */
+  int64_t duplicate_evals;     /* evaluations discarded by revert_visits! (mcts.jl:173)  */
+  int64_t terminal_visits;     /* select_leaf hits on finished positions                */
+  int64_t root_visits;         /* sum of N(root) increments                             */
+  int64_t nodes_in_use;
+  int64_t pool_exhausted;      /* >0 => results invalid, raise max_nodes_per_game       */
+  int64_t resigned_games;
+  int64_t live_games;
+} agz_stats;
+agz_status agz_engine_stats(agz_engine* e, agz_stats* out);            /* synchronises */
+/* external-network mode (MCTSPlayer.network duck typing, mcts_play.jl:5,89): after a step's
+ * select phase the caller reads the leaf feature tensor and supplies pi/v. */
+agz_status agz_selfplay_select(agz_engine* e, int32_t* nleaves_out);
+agz_status agz_selfplay_leaf_features(agz_engine* e, float* feats_out /* N x N x 17 x B */);
+agz_status agz_selfplay_incorporate(agz_engine* e, const float* pi /* A x B */, const float* v);
+
+/* finished-game records: extract_data(player), mcts_play.jl:126-139 */
+typedef struct {
+  uint64_t game_id;
+  int32_t num_moves;           /* position.n == length(searches_pi)                      */
+  int32_t result;              /* +1 Black, -1 White, 0 draw (Black-absolute)             */
+  int32_t was_resign;
+  int32_t resign_disabled;
+  float final_score;           /* score(position) when not resigned                       */
+  int32_t reserved;
+} agz_game_header;
+int64_t agz_records_count(agz_engine* e);                               /* synchronises */
+agz_status agz_records_header(agz_engine* e, int64_t k, agz_game_header* out);
+/* moves int16[num_moves] (action index), pis float[num_moves][A], qs float[num_moves] */
+agz_status agz_records_game(agz_engine* e, int64_t k, int16_t* moves, float* pis, float* qs);
+/* packed export for the replay all-gather: writes every finished record as
+ * [header | moves | pis | qs] back to back; returns bytes via nbytes_out. dst may be a host
+ * or a device pointer (is_device). */
+agz_status agz_records_packed_size(agz_engine* e, int64_t* nbytes_out);
+agz_status agz_records_export_packed(agz_engine* e, void* dst, int64_t capacity, int32_t is_device);
+agz_status agz_records_clear(agz_engine* e);
+/* replay_position(pos, result) board.jl:557-578 on the device: rebuild the feature tensors of
+ * every position of record k: out float[num_moves][N*N*17] (WHC per position) */
+agz_status agz_records_features(agz_engine* e, int64_t k, float* out);
+
+/* ---------------------------------------------------------------- single-tree compat ---- */
+/* The reference's MCTSPlayer / MCTSNode API on game slot g (tests drive these one call at a
+ * time exactly like test/test_mcts.jl and test/test_mcts_player.jl).  Node handles are
+ * slot-local int32 ids; the root is whatever agz_tree_root returns. */
+typedef struct {
+  int32_t n;                   /* moves played so far                                   */
+  int32_t to_play;
+  int32_t ko;                  /* -1 none                                               */
+  int32_t caps_black, caps_white;
+  int32_t last_move;           /* -1 none, N*N pass  (recent[end].move)                 */
+  int32_t prev_move;           /* -1 none            (recent[end-1].move)               */
+  int32_t history_len;         /* boards of real history available before this one (<=7) */
+  float komi;
+} agz_position_info;
+/* initialize_game!(player, pos) mcts_play.jl:110-118; history = int8[history_len][N*N] older
+ * boards newest first (NULL when history_len == 0) */
+agz_status agz_tree_init(agz_engine* e, int32_t g, const int8_t* board, const agz_position_info* info,
+                         const int8_t* history);
+agz_status agz_tree_root(agz_engine* e, int32_t g, int32_t* node_out);
+agz_status agz_tree_select_leaf(agz_engine* e, int32_t g, int32_t from_node, int32_t* leaf_out);
+agz_status agz_tree_maybe_add_child(agz_engine* e, int32_t g, int32_t node, int32_t a, int32_t* child_out);
+agz_status agz_tree_add_virtual_loss(agz_engine* e, int32_t g, int32_t node, int32_t up_to);
+agz_status agz_tree_revert_virtual_loss(agz_engine* e, int32_t g, int32_t node, int32_t up_to);
+agz_status agz_tree_incorporate(agz_engine* e, int32_t g, int32_t node, const float* probs,
+                                int32_t nprobs, float value, int32_t up_to);
+agz_status agz_tree_inject_noise(agz_engine* e, int32_t g, int32_t node);
+/* tree_search!(player, parallel_readouts): select phase then (with an internal network) the
+ * evaluation and incorporate phases; returns the number of leaves */
+agz_status agz_tree_search(agz_engine* e, int32_t g, int32_t parallel_readouts, int32_t* nleaves_out);
+agz_status agz_tree_pick_move(agz_engine* e, int32_t g, int32_t* a_out);
+agz_status agz_tree_play_move(agz_engine* e, int32_t g, int32_t a, int32_t* ok_out);
+agz_status agz_tree_should_resign(agz_engine* e, int32_t g, int32_t* out);
+agz_status agz_tree_is_done(agz_engine* e, int32_t g, int32_t node, int32_t* out);
+typedef struct {
+  float N, W, Q;
+  int32_t parent, fmove, is_expanded, losses_applied, done;
+  agz_position_info pos;
+} agz_node_info;
+agz_status agz_tree_node_info(agz_engine* e, int32_t g, int32_t node, agz_node_info* out);
+#define AGZ_F_CHILD_N 0
+#define AGZ_F_CHILD_W 1
+#define AGZ_F_CHILD_PRIOR 2
+#define AGZ_F_ACTION_SCORE 3     /* Float64 scores narrowed to double[A] */
+agz_status agz_tree_node_floats(agz_engine* e, int32_t g, int32_t node, int32_t field, float* out);
+agz_status agz_tree_node_scores(agz_engine* e, int32_t g, int32_t node, double* out);
+agz_status agz_tree_node_set_floats(agz_engine* e, int32_t g, int32_t node, int32_t field, const float* in);
+agz_status agz_tree_node_set_N(agz_engine* e, int32_t g, int32_t node, float value);
+agz_status agz_tree_node_set_n(agz_engine* e, int32_t g, int32_t node, int32_t n);
+agz_status agz_tree_node_children(agz_engine* e, int32_t g, int32_t node, int32_t* out /* [A] */);
+agz_status agz_tree_node_board(agz_engine* e, int32_t g, int32_t node, int8_t* out /* [N*N] */);
+agz_status agz_tree_pending_vlosses(agz_engine* e, int32_t g, int32_t* out);
+agz_status agz_tree_set_draw(agz_engine* e, int32_t g, uint64_t game_id, uint32_t sel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGZ_H */

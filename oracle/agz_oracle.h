@@ -165,6 +165,9 @@ int or_player_extract_data(const OPlayer* p, OPos* positions, float* pis, int* r
 /* ---- selfplay, src/selfplay.jl:1-45 (with the D2 ternary typo read as intended) ---- */
 OPlayer* or_selfplay(int N, or_net_fn net, void* net_ctx, int num_readouts, uint64_t seed,
                      uint64_t game, int max_moves /* <=0: play to the end */);
+/* same with the resign threshold (-0.9) and the resign-disable fraction (0.05) exposed */
+OPlayer* or_selfplay_ex(int N, or_net_fn net, void* net_ctx, int num_readouts, uint64_t seed,
+                        uint64_t game, int max_moves, double threshold, double disable_fraction);
 
 /* ---- network, src/neural_net.jl:13-33,57-73 + src/resnet.jl:11-32 ---- */
 typedef struct ONet ONet;

@@ -455,10 +455,10 @@ int or_player_extract_data(const OPlayer* p, OPos* positions, float* pis, int* r
 
 /* selfplay, selfplay.jl:1-45.  resign_threshold: "rand() < 0.05 : -1.0 : -0.9" is read as
  * the intended ternary. */
-OPlayer* or_selfplay(int N, or_net_fn net, void* net_ctx, int num_readouts, uint64_t seed,
-                     uint64_t game, int max_moves) {
+OPlayer* or_selfplay_ex(int N, or_net_fn net, void* net_ctx, int num_readouts, uint64_t seed,
+                        uint64_t game, int max_moves, double threshold, double disable_fraction) {
   double u = agz_u01(agz_draw_u64(seed, game, 0, AGZ_SITE_RESIGN, 0));
-  double resign_threshold = u < 0.05 ? -1.0 : -0.9;
+  double resign_threshold = u < disable_fraction ? -1.0 : threshold;
   OPlayer* p = or_player_new(N, net, net_ctx, num_readouts, 0, resign_threshold, seed, game);
   int A = p->env.A;
   or_player_initialize_game(p, NULL);
@@ -496,6 +496,11 @@ OPlayer* or_selfplay(int N, or_net_fn net, void* net_ctx, int num_readouts, uint
     if (max_moves > 0 && moves >= max_moves) break;
   }
   return p;
+}
+
+OPlayer* or_selfplay(int N, or_net_fn net, void* net_ctx, int num_readouts, uint64_t seed,
+                     uint64_t game, int max_moves) {
+  return or_selfplay_ex(N, net, net_ctx, num_readouts, seed, game, max_moves, -0.9, 0.05);
 }
 
 /* ---- thin exports of the draw-stream header for tests/test_draws.py ---- */

@@ -139,6 +139,7 @@ def lib():
         "or_player_evals": (u64, [vp]),
         "or_player_extract_data": (i, [vp, P(OPos), P(f), P(i)]),
         "or_selfplay": (vp, [i, NET_FN, vp, i, u64, u64, i]),
+        "or_selfplay_ex": (vp, [i, NET_FN, vp, i, u64, u64, i, d, d]),
         "or_net_new": (vp, [i, i]),
         "or_net_free": (None, [vp]),
         "or_net_set": (i, [vp, i, i, P(f), C.c_int64]),
