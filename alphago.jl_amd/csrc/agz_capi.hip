@@ -1,0 +1,380 @@
+// agz_capi.hip -- the extern "C" surface of libagz.so (include/agz.h): argument checks,
+// exception -> status translation, nothing else.
+#include <cstring>
+#include <string>
+
+#include "agz_engine.h"
+#include "agz_search.h"
+
+struct agz_engine {
+  agz::Engine* impl;
+  std::string err;
+};
+
+namespace {
+std::string g_create_error;
+
+template <class F>
+agz_status guard(agz_engine* e, F&& f) {
+  if (!e || !e->impl) return AGZ_BAD_ARGUMENT;
+  try {
+    f(*e->impl);
+    return AGZ_OK;
+  } catch (const agz::Error& x) {
+    e->err = x.what();
+    return x.status;
+  } catch (const std::exception& x) {
+    e->err = x.what();
+    return AGZ_BAD_ARGUMENT;
+  }
+}
+
+// like guard, but the callable returns a reference-level status (IllegalMove, assertion ...)
+template <class F>
+agz_status guard_status(agz_engine* e, F&& f) {
+  if (!e || !e->impl) return AGZ_BAD_ARGUMENT;
+  try {
+    const int st = f(*e->impl);
+    if (st != AGZ_OK) e->err = "reference-level condition " + std::to_string(st);
+    return st;
+  } catch (const agz::Error& x) {
+    e->err = x.what();
+    return x.status;
+  } catch (const std::exception& x) {
+    e->err = x.what();
+    return AGZ_BAD_ARGUMENT;
+  }
+}
+
+agz::TreeArgs targs(int op, int g, int node = 0, int a = 0, int up_to = -1) {
+  agz::TreeArgs T;
+  std::memset(&T, 0, sizeof(T));
+  T.op = op; T.g = g; T.node = node; T.a = a; T.up_to = up_to;
+  return T;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t agz_version(void) { return AGZ_VERSION; }
+
+void agz_config_default(agz_config* c) {
+  std::memset(c, 0, sizeof(*c));
+  c->board_size = 19;          // GoEnv(board_size = 19), go.jl:10
+  c->tower_height = 19;        // NeuralNet(env; tower_height = 19), neural_net.jl:13
+  c->games = 1;
+  c->num_readouts = 800;       // mcts_play.jl:17
+  c->parallel_readouts = 8;    // mcts_play.jl:73
+  c->two_player_mode = 0;
+  c->komi = 7.5f;              // board.jl:297
+  c->c_puct = 0.96;            // mcts.jl:11
+  c->dirichlet_noise_weight = 0.25;   // mcts.jl:13
+  c->resign_threshold = -0.9;  // mcts_play.jl:18
+  c->resign_disable_fraction = 0.05;  // selfplay.jl:9
+  c->seed = 0;
+  c->game_id_base = 0;
+  c->game_id_stride = 1;
+}
+
+agz_status agz_engine_create(const agz_config* cfg, agz_engine** out) {
+  if (!cfg || !out) return AGZ_BAD_ARGUMENT;
+  *out = nullptr;
+  try {
+    agz_engine* e = new agz_engine{nullptr, {}};
+    e->impl = new agz::Engine(*cfg);
+    *out = e;
+    return AGZ_OK;
+  } catch (const agz::Error& x) {
+    g_create_error = x.what();
+    return x.status;
+  } catch (const std::exception& x) {
+    g_create_error = x.what();
+    return AGZ_BAD_ARGUMENT;
+  }
+}
+
+void agz_engine_destroy(agz_engine* e) {
+  if (!e) return;
+  delete e->impl;
+  delete e;
+}
+
+const char* agz_last_error(const agz_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+agz_status agz_engine_sync(agz_engine* e) { return guard(e, [&](agz::Engine& E) { E.sync(); }); }
+
+// ---- network
+agz_status agz_net_set_weights(agz_engine* e, int32_t layer, int32_t kind, const float* data, int64_t count) {
+  return guard(e, [&](agz::Engine& E) { E.net().set(layer, kind, data, count); });
+}
+int64_t agz_net_param_count(const agz_engine* e, int32_t layer, int32_t kind) {
+  if (!e || !e->impl) return -1;
+  return e->impl->net().param_count(layer, kind);
+}
+agz_status agz_net_init_synthetic(agz_engine* e, uint64_t seed) {
+  return guard(e, [&](agz::Engine& E) { E.net().init_synthetic(seed); });
+}
+agz_status agz_net_forward(agz_engine* e, const int8_t* boards, const int8_t* deltas, const int32_t* ndeltas,
+                           const int8_t* to_play, int32_t B, float* pi_out, float* v_out) {
+  return guard(e, [&](agz::Engine& E) { E.net_forward_positions(boards, deltas, ndeltas, to_play, B, pi_out, v_out); });
+}
+agz_status agz_net_forward_features(agz_engine* e, const float* feats, int32_t B, float* pi_out, float* v_out) {
+  return guard(e, [&](agz::Engine& E) { E.net_forward_features(feats, B, pi_out, v_out); });
+}
+agz_status agz_features(agz_engine* e, const int8_t* boards, const int8_t* deltas, const int32_t* ndeltas,
+                        const int8_t* to_play, int32_t B, float* out) {
+  return guard(e, [&](agz::Engine& E) { E.features(boards, deltas, ndeltas, to_play, B, out); });
+}
+agz_status agz_net_time_forward(agz_engine* e, int32_t B, int32_t iters, float* ms_out) {
+  return guard(e, [&](agz::Engine& E) { *ms_out = E.time_forward(B, iters); });
+}
+agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_out) {
+  return guard(e, [&](agz::Engine& E) { *ms_out = E.time_conv(B, iters); });
+}
+
+agz_status agz_profile_conv_enable(agz_engine* e, int32_t on) {
+  return guard(e, [&](agz::Engine& E) { E.net().profile_enable(on != 0); });
+}
+agz_status agz_profile_conv_read(agz_engine* e, double* total_ms, double* total_flop, int64_t* launches) {
+  return guard(e, [&](agz::Engine& E) { E.net().profile_read(total_ms, total_flop, launches); });
+}
+
+// ---- Go rules
+agz_status agz_go_play(agz_engine* e, const int8_t* boards, const int8_t* to_play, const int32_t* ko,
+                       const int32_t* moves, int32_t B, int8_t* boards_out, int32_t* ko_out,
+                       int32_t* ncaptured_out, int32_t* status_out) {
+  return guard(e, [&](agz::Engine& E) { E.go_play(boards, to_play, ko, moves, B, boards_out, ko_out, ncaptured_out, status_out); });
+}
+agz_status agz_go_legal(agz_engine* e, const int8_t* boards, const int8_t* to_play, const int32_t* ko, int32_t B,
+                        int8_t* legal_out) {
+  return guard(e, [&](agz::Engine& E) { E.go_legal(boards, to_play, ko, B, legal_out); });
+}
+agz_status agz_go_score(agz_engine* e, const int8_t* boards, const float* komi, int32_t B, float* score_out) {
+  return guard(e, [&](agz::Engine& E) { E.go_score(boards, komi, B, score_out); });
+}
+
+// ---- batched self-play
+agz_status agz_selfplay_start(agz_engine* e, int64_t total_games) {
+  return guard(e, [&](agz::Engine& E) { E.start(total_games); });
+}
+agz_status agz_selfplay_step(agz_engine* e, int32_t nsteps) {
+  return guard(e, [&](agz::Engine& E) { E.step(nsteps); });
+}
+agz_status agz_engine_stats(agz_engine* e, agz_stats* out) {
+  return guard(e, [&](agz::Engine& E) { E.stats(out); });
+}
+agz_status agz_selfplay_select(agz_engine* e, int32_t* nleaves_out) {
+  return guard(e, [&](agz::Engine& E) { *nleaves_out = E.select_external(); });
+}
+agz_status agz_selfplay_leaf_features(agz_engine* e, float* feats_out) {
+  return guard(e, [&](agz::Engine& E) { E.leaf_features_external(feats_out); });
+}
+agz_status agz_selfplay_incorporate(agz_engine* e, const float* pi, const float* v) {
+  return guard(e, [&](agz::Engine& E) { E.incorporate_external(pi, v); });
+}
+
+// ---- records
+int64_t agz_records_count(agz_engine* e) {
+  int64_t n = -1;
+  guard(e, [&](agz::Engine& E) { n = E.records_count(); });
+  return n;
+}
+agz_status agz_records_header(agz_engine* e, int64_t k, agz_game_header* out) {
+  return guard(e, [&](agz::Engine& E) { E.record_header(k, out); });
+}
+agz_status agz_records_game(agz_engine* e, int64_t k, int16_t* moves, float* pis, float* qs) {
+  return guard(e, [&](agz::Engine& E) { E.record_game(k, moves, pis, qs); });
+}
+agz_status agz_records_packed_size(agz_engine* e, int64_t* nbytes_out) {
+  return guard(e, [&](agz::Engine& E) { *nbytes_out = E.records_packed_size(); });
+}
+agz_status agz_records_export_packed(agz_engine* e, void* dst, int64_t capacity, int32_t is_device) {
+  return guard(e, [&](agz::Engine& E) { E.records_export_packed(dst, capacity, is_device != 0); });
+}
+agz_status agz_records_clear(agz_engine* e) { return guard(e, [&](agz::Engine& E) { E.records_clear(); }); }
+agz_status agz_records_features(agz_engine* e, int64_t k, float* out) {
+  return guard(e, [&](agz::Engine& E) { E.record_features(k, out); });
+}
+
+// ---- single-tree compat
+agz_status agz_tree_init(agz_engine* e, int32_t g, const int8_t* board, const agz_position_info* info,
+                         const int8_t* history) {
+  return guard_status(e, [&](agz::Engine& E) {
+    AGZ_REQUIRE(board && info, AGZ_BAD_ARGUMENT, "agz_tree_init: null board/info");
+    agz::TreeArgs T = targs(agz::TOP_INIT, g);
+    T.info = *info;
+    T.board = board;
+    T.history = history;
+    return E.tree_op(T, nullptr);
+  });
+}
+agz_status agz_tree_root(agz_engine* e, int32_t g, int32_t* node_out) {
+  return guard(e, [&](agz::Engine& E) {
+    agz::GameState s;
+    E.game_state(g, &s);
+    *node_out = s.root;
+  });
+}
+agz_status agz_tree_select_leaf(agz_engine* e, int32_t g, int32_t from_node, int32_t* leaf_out) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_SELECT, g, from_node);
+    return E.tree_op(T, leaf_out);
+  });
+}
+agz_status agz_tree_maybe_add_child(agz_engine* e, int32_t g, int32_t node, int32_t a, int32_t* child_out) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_ADD_CHILD, g, node, a);
+    return E.tree_op(T, child_out);
+  });
+}
+agz_status agz_tree_add_virtual_loss(agz_engine* e, int32_t g, int32_t node, int32_t up_to) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_VLOSS_ADD, g, node, 0, up_to);
+    return E.tree_op(T, nullptr);
+  });
+}
+agz_status agz_tree_revert_virtual_loss(agz_engine* e, int32_t g, int32_t node, int32_t up_to) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_VLOSS_REVERT, g, node, 0, up_to);
+    return E.tree_op(T, nullptr);
+  });
+}
+agz_status agz_tree_incorporate(agz_engine* e, int32_t g, int32_t node, const float* probs, int32_t nprobs,
+                                float value, int32_t up_to) {
+  return guard_status(e, [&](agz::Engine& E) {
+    if (nprobs != E.view().A) return (int)AGZ_BAD_SHAPE;   // @assert size(move_probs) == (A,), mcts.jl:190
+    agz::TreeArgs T = targs(agz::TOP_INCORPORATE, g, node, 0, up_to);
+    T.probs = probs;
+    T.value = value;
+    return E.tree_op(T, nullptr);
+  });
+}
+agz_status agz_tree_inject_noise(agz_engine* e, int32_t g, int32_t node) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_NOISE, g, node);
+    return E.tree_op(T, nullptr);
+  });
+}
+agz_status agz_tree_search_select(agz_engine* e, int32_t g, int32_t par, int32_t* nleaves_out) {
+  return guard_status(e, [&](agz::Engine& E) { return E.tree_search_select(g, par, nleaves_out); });
+}
+agz_status agz_tree_leaf_features(agz_engine* e, int32_t g, float* feats_out) {
+  return guard(e, [&](agz::Engine& E) { E.tree_leaf_features(g, feats_out); });
+}
+agz_status agz_tree_search_incorporate(agz_engine* e, int32_t g, const float* pi, const float* v) {
+  return guard_status(e, [&](agz::Engine& E) { return E.tree_search_incorporate(g, pi, v); });
+}
+agz_status agz_tree_search(agz_engine* e, int32_t g, int32_t par, int32_t* nleaves_out) {
+  return guard_status(e, [&](agz::Engine& E) {
+    const int st = E.tree_search_select(g, par, nleaves_out);
+    if (st != AGZ_OK) return st;
+    return E.tree_search_incorporate(g, nullptr, nullptr);
+  });
+}
+agz_status agz_tree_pick_move(agz_engine* e, int32_t g, int32_t* a_out) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_PICK, g);
+    return E.tree_op(T, a_out);
+  });
+}
+agz_status agz_tree_play_move(agz_engine* e, int32_t g, int32_t a, int32_t* ok_out) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_PLAY, g, 0, a);
+    return E.tree_op(T, ok_out);
+  });
+}
+agz_status agz_tree_should_resign(agz_engine* e, int32_t g, int32_t* out) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_RESIGN, g);
+    return E.tree_op(T, out);
+  });
+}
+agz_status agz_tree_is_done(agz_engine* e, int32_t g, int32_t node, int32_t* out) {
+  return guard(e, [&](agz::Engine& E) {
+    agz::NodeMeta m;
+    E.node_meta(g, node, &m);
+    *out = (m.flags & agz::NF_DONE) || m.n >= E.view().max_game_length;   // mcts.jl:230-231
+  });
+}
+agz_status agz_tree_node_info(agz_engine* e, int32_t g, int32_t node, agz_node_info* out) {
+  return guard(e, [&](agz::Engine& E) {
+    agz::NodeMeta m;
+    agz::GameState s;
+    E.node_meta(g, node, &m);
+    E.game_state(g, &s);
+    std::memset(out, 0, sizeof(*out));
+    out->N = E.node_stat(g, node, 0);
+    out->W = E.node_stat(g, node, 1);
+    out->Q = out->W / (1.0f + out->N);
+    out->parent = m.parent;
+    out->fmove = m.fmove;
+    out->is_expanded = (m.flags & agz::NF_EXPANDED) != 0;
+    out->losses_applied = m.losses;
+    out->done = (m.flags & agz::NF_DONE) != 0;
+    out->pos.n = m.n;
+    out->pos.to_play = m.to_play;
+    out->pos.ko = m.ko;
+    out->pos.caps_black = m.caps_b;
+    out->pos.caps_white = m.caps_w;
+    out->pos.last_move = m.last_move;
+    out->pos.prev_move = -1;
+    out->pos.history_len = s.hist_len;
+    out->pos.komi = s.komi;
+  });
+}
+agz_status agz_tree_node_floats(agz_engine* e, int32_t g, int32_t node, int32_t field, float* out) {
+  return guard(e, [&](agz::Engine& E) { E.node_row_get(g, node, field, out); });
+}
+agz_status agz_tree_node_scores(agz_engine* e, int32_t g, int32_t node, double* out) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_SCORES, g, node);
+    T.dout = out;
+    return E.tree_op(T, nullptr);
+  });
+}
+agz_status agz_tree_node_set_floats(agz_engine* e, int32_t g, int32_t node, int32_t field, const float* in) {
+  return guard(e, [&](agz::Engine& E) { E.node_row_set(g, node, field, in); });
+}
+agz_status agz_tree_node_set_N(agz_engine* e, int32_t g, int32_t node, float value) {
+  return guard(e, [&](agz::Engine& E) { E.node_set_N(g, node, value); });
+}
+agz_status agz_tree_node_set_n(agz_engine* e, int32_t g, int32_t node, int32_t n) {
+  return guard(e, [&](agz::Engine& E) {
+    agz::NodeMeta m;
+    E.node_meta(g, node, &m);
+    m.n = n;
+    E.node_meta_set(g, node, m);
+  });
+}
+agz_status agz_tree_node_children(agz_engine* e, int32_t g, int32_t node, int32_t* out) {
+  return guard(e, [&](agz::Engine& E) { E.node_children(g, node, out); });
+}
+agz_status agz_tree_node_board(agz_engine* e, int32_t g, int32_t node, int8_t* out) {
+  return guard(e, [&](agz::Engine& E) { E.node_board(g, node, out); });
+}
+agz_status agz_tree_pending_vlosses(agz_engine* e, int32_t g, int32_t* out) {
+  return guard_status(e, [&](agz::Engine& E) {
+    agz::TreeArgs T = targs(agz::TOP_PENDING, g);
+    return E.tree_op(T, out);
+  });
+}
+agz_status agz_tree_set_draw(agz_engine* e, int32_t g, uint64_t game_id, uint32_t sel) {
+  return guard(e, [&](agz::Engine& E) {
+    agz::GameState s;
+    E.game_state(g, &s);
+    s.game_id = game_id;
+    s.sel = (int32_t)sel;
+    E.game_patch(g, s);
+  });
+}
+
+// ---- diagnostics
+agz_status agz_debug_draws(agz_engine* e, uint64_t seed, uint64_t game, uint32_t move, int32_t n, double alpha,
+                           double* gamma_out) {
+  return guard(e, [&](agz::Engine& E) { E.debug_draws(seed, game, move, n, alpha, gamma_out); });
+}
+agz_status agz_debug_math(agz_engine* e, int32_t op, const double* x, const double* y, int32_t n, double* out) {
+  return guard(e, [&](agz::Engine& E) { E.debug_math(op, x, y, n, out); });
+}
+
+}  // extern "C"

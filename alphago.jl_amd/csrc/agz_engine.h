@@ -1,0 +1,105 @@
+// agz_engine.h -- host-side engine object behind the C ABI (include/agz.h).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "agz_common.h"
+#include "agz_layout.h"
+#include "agz_nn.h"
+#include "agz_state.h"
+
+namespace agz {
+
+struct TreeArgs;
+
+class Engine {
+ public:
+  explicit Engine(const agz_config& cfg);
+  ~Engine();
+
+  const agz_config& config() const { return cfg_; }
+  const View& view() const { return V_; }
+  Net& net() { return *net_; }
+  hipStream_t stream() const { return stream_; }
+  void sync();
+
+  // batched self-play
+  void start(int64_t total_games);
+  void step(int nsteps);
+  void stats(agz_stats* out);
+  int select_external();
+  void leaf_features_external(float* feats_out);
+  void incorporate_external(const float* pi, const float* v);
+
+  // records
+  int64_t records_count();
+  void record_header(int64_t k, agz_game_header* out);
+  void record_game(int64_t k, int16_t* moves, float* pis, float* qs);
+  int64_t records_packed_size();
+  void records_export_packed(void* dst, int64_t capacity, bool is_device);
+  void records_clear();
+  void record_features(int64_t k, float* out);
+
+  // network
+  void net_forward_positions(const int8_t* boards, const int8_t* deltas, const int32_t* ndeltas,
+                             const int8_t* to_play, int B, float* pi_out, float* v_out);
+  void net_forward_features(const float* feats, int B, float* pi_out, float* v_out);
+  void features(const int8_t* boards, const int8_t* deltas, const int32_t* ndeltas, const int8_t* to_play,
+                int B, float* out);
+  float time_forward(int B, int iters);
+  float time_conv(int B, int iters);
+
+  void debug_draws(uint64_t seed, uint64_t game, uint32_t move, int n, double alpha, double* out);
+  void debug_math(int op, const double* x, const double* y, int n, double* out);
+
+  // Go rules
+  void go_play(const int8_t* boards, const int8_t* to_play, const int32_t* ko, const int32_t* moves, int B,
+               int8_t* boards_out, int32_t* ko_out, int32_t* ncap_out, int32_t* status_out);
+  void go_legal(const int8_t* boards, const int8_t* to_play, const int32_t* ko, int B, int8_t* out);
+  void go_score(const int8_t* boards, const float* komi, int B, float* out);
+
+  // single-tree compat
+  int tree_op(TreeArgs& T, int32_t* r0);           // returns the op's agz_status
+  int tree_search_select(int g, int par, int* nleaves);
+  void tree_leaf_features(int g, float* feats_out);
+  int tree_search_incorporate(int g, const float* pi, const float* v);   // pi == NULL: engine's own network
+  void game_state(int g, GameState* out);
+  void game_patch(int g, const GameState& s);
+  void node_meta(int g, int node, NodeMeta* out);
+  void node_meta_set(int g, int node, const NodeMeta& m);
+  void node_row_get(int g, int node, int field, float* out);
+  void node_row_set(int g, int node, int field, const float* in);
+  void node_children(int g, int node, int32_t* out);
+  void node_board(int g, int node, int8_t* out);
+  float node_stat(int g, int node, int which);     // 0 = N, 1 = W
+  void node_set_N(int g, int node, float v);
+
+  std::string last_error;
+
+ private:
+  void upload_view_outputs();
+  void fill_synthetic_inputs(int B);
+  void check_game(int g) const;
+  void check_node(int g, int node) const;
+
+  agz_config cfg_;
+  View V_{};
+  hipStream_t stream_ = nullptr;
+  std::unique_ptr<Net> net_;
+  std::vector<void*> bufs_;
+  size_t state_bytes_ = 0;
+  int bcap_ = 0;
+  DevBuf<float> d_x32_, d_pi_, d_v_, d_whcn_;
+  DevBuf<int32_t> d_count_;
+  // staging for ABI calls
+  DevBuf<int8_t> s_boards_, s_deltas_, s_tp_, s_boards_out_, s_legal_;
+  DevBuf<int32_t> s_i32a_, s_i32b_, s_i32c_, s_i32d_;
+  DevBuf<float> s_f32a_, s_f32b_;
+  DevBuf<double> s_f64_;
+  DevBuf<int32_t> s_iout_;
+  int external_batch_ = 0;
+  int tree_batch_ = 0;
+};
+
+}  // namespace agz

@@ -1,0 +1,828 @@
+// agz_engine.hip -- the HIP instantiation of the search templates (one 64-lane wavefront per
+// game tree) and the host engine that strings a self-play step together:
+//
+//   k_pre            lifecycle + per-move phase + select up to 8 leaves     (1 wave / game)
+//   k_scan           prefix sum of the leaf counts -> rows of the NN batch
+//   k_leaf_features  17 board planes of every leaf -> stem input            (1 wave / leaf)
+//   Net::forward     stem + tower (MFMA implicit GEMM) + heads              (agz_nn.hip)
+//   k_post           revert virtual loss, expand, back up                   (1 wave / game)
+//
+// Everything is enqueued on one stream with the batch size left in device memory, so a step
+// needs no host synchronisation.  Compiled with -ffp-contract=off: the PUCT arithmetic mixes
+// Float32 and Float64 exactly as the reference does.
+#include "agz_engine.h"
+
+#include <algorithm>
+#include <cstring>
+
+#include "agz_search.h"
+
+namespace agz {
+
+// ------------------------------------------------------------------ the wave primitives on gfx950
+
+struct HipWave {
+  int lane;
+  __device__ HipWave() : lane((int)threadIdx.x) {}
+  template <class F>
+  __device__ __forceinline__ void for_each(int n, F f) const {
+    for (int i = lane; i < n; i += kWave) f(i);
+  }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ bool leader() const { return lane == 0; }
+  __device__ __forceinline__ int reduce_sum(int v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+  }
+  __device__ __forceinline__ int reduce_min(int v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, kWave); v = t < v ? t : v; }
+    return v;
+  }
+  __device__ __forceinline__ int reduce_max(int v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, kWave); v = t > v ? t : v; }
+    return v;
+  }
+  __device__ __forceinline__ double reduce_max(double v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o, kWave); v = t > v ? t : v; }
+    return v;
+  }
+  __device__ __forceinline__ float reduce_sum_f(float v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+  }
+  __device__ __forceinline__ float reduce_max_f(float v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(v, o, kWave); v = t > v ? t : v; }
+    return v;
+  }
+  __device__ __forceinline__ bool any(bool v) const { return __any(v) != 0; }
+  __device__ __forceinline__ void amin(int32_t* p, int v) const { atomicMin(p, v); }
+  __device__ __forceinline__ void amax(int32_t* p, int v) const { atomicMax(p, v); }
+  __device__ __forceinline__ void aor(int32_t* p, int v) const { atomicOr(p, v); }
+  __device__ __forceinline__ void count(unsigned long long* p, unsigned long long v) const {
+    if (lane == 0 && v) atomicAdd(p, v);
+  }
+  __device__ __forceinline__ unsigned long long fetch_add(unsigned long long* p, unsigned long long v) const {
+    unsigned long long r = 0;
+    if (lane == 0) r = atomicAdd(p, v);
+    const unsigned lo = __shfl((unsigned)(r & 0xffffffffull), 0, kWave);
+    const unsigned hi = __shfl((unsigned)(r >> 32), 0, kWave);
+    return ((unsigned long long)hi << 32) | lo;
+  }
+};
+
+constexpr int kPPMax = 368, kAPMax = 368, kMaxdMax = 528;
+
+#define AGZ_SCRATCH(S)                                                        \
+  __shared__ int8_t s_sb[kPPMax];                                             \
+  __shared__ int32_t s_label[kPPMax + kWave];                                 \
+  __shared__ int32_t s_minlib[kPPMax];                                        \
+  __shared__ int32_t s_maxlib[kPPMax];                                        \
+  __shared__ int8_t s_flag[kAPMax];                                           \
+  __shared__ double s_dbuf[kAPMax];                                           \
+  __shared__ int32_t s_path[kMaxdMax];                                        \
+  Scratch S{s_sb, s_label, s_minlib, s_maxlib, s_flag, s_dbuf, s_path};
+
+__global__ __launch_bounds__(kWave) void k_pre(View V) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  game_pre(w, V, S, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(kWave) void k_post(View V) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  game_post(w, V, S, (int)blockIdx.x);
+}
+
+// exclusive prefix sum of GameState::nleaves over the games -> leaf_base, total -> batch_count
+__global__ __launch_bounds__(256) void k_scan(View V) {
+  __shared__ int part[256];
+  const int t = threadIdx.x, G = V.games;
+  const int chunk = (G + 255) / 256;
+  const int lo = t * chunk, hi = min(G, lo + chunk);
+  int s = 0;
+  for (int g = lo; g < hi; ++g) s += V.gs[g].nleaves;
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int base = part[t] - s;
+  for (int g = lo; g < hi; ++g) {
+    V.gs[g].leaf_base = base;
+    base += V.gs[g].nleaves;
+  }
+  if (t == 255) {
+    *V.batch_count = part[255];
+    atomicAdd(&V.counters[CT_STEPS], 1ull);
+  }
+}
+
+__global__ __launch_bounds__(kWave) void k_leaf_features(View V, int g0, float* x32, float* whcn) {
+  const int g = g0 + blockIdx.x / V.par, k = blockIdx.x % V.par;
+  if (k >= V.gs[g].nleaves) return;
+  HipWave w;
+  const long row = (long)V.gs[g].leaf_base + k;
+  leaf_features(w, V, g, k, x32 ? x32 + row * V.P * 32 : nullptr, whcn ? whcn + row * 17 * V.P : nullptr);
+}
+
+__global__ __launch_bounds__(kWave) void k_tree_op(View V, TreeArgs T) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  tree_op(w, V, S, T);
+}
+
+__global__ __launch_bounds__(kWave) void k_go_play(View V, const int8_t* boards, const int8_t* tp, const int32_t* ko,
+                                                    const int32_t* moves, int B, int8_t* bo, int32_t* ko_o,
+                                                    int32_t* nc, int32_t* st) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  go_play_one(w, V, S, boards + (long)b * V.P, tp[b], ko[b], moves[b], bo + (long)b * V.P, ko_o + b, nc + b, st + b);
+}
+
+__global__ __launch_bounds__(kWave) void k_go_legal(View V, const int8_t* boards, const int8_t* tp,
+                                                     const int32_t* ko, int B, int8_t* out) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  go_legal_one(w, V, S, boards + (long)b * V.P, tp[b], ko[b], out + (long)b * V.A);
+}
+
+__global__ __launch_bounds__(kWave) void k_go_score(View V, const int8_t* boards, const float* komi, int B, float* out) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  go_score_one(w, V, S, boards + (long)b * V.P, komi[b], out + b);
+}
+
+// replay_position (board.jl:557-578) on the device: rebuild the 17 planes of every position of
+// a finished game from its move list.  One wave walks the game; out is [num_moves][17*P].
+__global__ __launch_bounds__(kWave) void k_replay_features(View V, const int16_t* moves, int nm, float komi,
+                                                            int8_t* hist /*[8][PP] scratch in HBM*/, float* out) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  const int P = V.P;
+  // hist[0] = current board, hist[k] = k moves ago; avail = number of real older boards
+  w.for_each(8 * V.PP, [&](int i) { hist[i] = 0; });
+  w.sync();
+  int tp = 1, ko = -1, avail = 0;
+  for (int k = 0; k < nm; ++k) {
+    w.for_each(P, [&](int p) {
+      float* dst = out + (long)k * 17 * P;
+      for (int s = 0; s < 8; ++s) {
+        const int t = s <= avail ? s : avail;
+        const int c = hist[t * V.PP + p];
+        dst[(2 * s) * P + p] = c == tp ? 1.f : 0.f;
+        dst[(2 * s + 1) * P + p] = c == -tp ? 1.f : 0.f;
+      }
+      dst[16 * P + p] = (float)tp;
+    });
+    w.sync();
+    // play move k on hist[0]
+    const int a = moves[k];
+    w.for_each(P, [&](int p) { S.sb[p] = hist[p]; });
+    w.sync();
+    int ncap = 0, nko = -1;
+    if (a != P) {
+      label_components(w, V, S, true);
+      group_liberties(w, V, S);
+      apply_move_in_scratch(w, V, S, a, tp, &ncap, &nko);
+    }
+    for (int s = 7; s >= 1; --s) {
+      w.for_each(P, [&](int p) { hist[s * V.PP + p] = hist[(s - 1) * V.PP + p]; });
+      w.sync();
+    }
+    w.for_each(P, [&](int p) { hist[p] = S.sb[p]; });
+    w.sync();
+    ko = nko;
+    tp = -tp;
+    if (avail < 7) avail++;
+  }
+  (void)ko; (void)komi;
+}
+
+__global__ void k_debug_draws(uint64_t seed, uint64_t game, uint32_t move, int n, double alpha, double* out) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < n) out[a] = agz_dirichlet_gamma(seed, game, move, (uint32_t)a, alpha);
+}
+
+__global__ void k_debug_math(View V, int op, const double* x, const double* y, int n, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r = 0.0;
+  switch (op) {
+    case 0: r = agz_log(x[i]); break;
+    case 1: r = agz_exp(x[i]); break;
+    case 2: r = agz_pow(x[i], 0.98); break;
+    case 3: r = (double)sqrtf((float)x[i]); break;
+    case 4: r = (double)((float)x[i] / (float)y[i]); break;
+    case 5: {
+      const float denom = 1.0f + (float)y[i];
+      const float q = (float)x[i] / denom;
+      const float qs = q * -1.0f;
+      const double scale = puct_scale(V, (float)y[i] + 7.0f);
+      r = (double)qs + (scale * (double)0.25f) / (double)denom;
+    } break;
+  }
+  out[i] = r;
+}
+
+// ------------------------------------------------------------------ host engine
+
+static void validate(const agz_config& c) {
+  AGZ_REQUIRE(c.board_size >= 2 && c.board_size <= 19, AGZ_BAD_ARGUMENT, "board_size %d not in 2..19", c.board_size);
+  AGZ_REQUIRE(c.tower_height >= 0 && c.tower_height <= 64, AGZ_BAD_ARGUMENT, "tower_height %d", c.tower_height);
+  AGZ_REQUIRE(c.games >= 1, AGZ_BAD_ARGUMENT, "games must be >= 1");
+  AGZ_REQUIRE(c.num_readouts >= 1, AGZ_BAD_ARGUMENT, "num_readouts must be >= 1");
+  AGZ_REQUIRE(c.parallel_readouts >= 1 && c.parallel_readouts <= kMaxPar, AGZ_BAD_ARGUMENT,
+              "parallel_readouts %d not in 1..%d", c.parallel_readouts, kMaxPar);
+}
+
+Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
+  validate(cfg);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  AGZ_REQUIRE(e == hipSuccess && ndev > 0, AGZ_HIP_ERROR,
+              "no HIP device available (%s): libagz has no CPU fallback", hipGetErrorString(e));
+  AGZ_REQUIRE(cfg.device >= 0 && cfg.device < ndev, AGZ_BAD_ARGUMENT, "device %d of %d", cfg.device, ndev);
+  AGZ_HIP(hipSetDevice(cfg.device));
+  hipDeviceProp_t prop;
+  AGZ_HIP(hipGetDeviceProperties(&prop, cfg.device));
+  AGZ_REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, AGZ_HIP_ERROR,
+              "device %d is %s; libagz is built for gfx950 (MI355X) only", cfg.device, prop.gcnArchName);
+  AGZ_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  fill_dims(V_, cfg);
+  AGZ_REQUIRE(V_.PP <= kPPMax && V_.AP <= kAPMax && V_.maxd <= kMaxdMax, AGZ_BAD_ARGUMENT, "board too large");
+  for_each_buffer(V_, [&](auto*& p, size_t n) {
+    using T = std::remove_reference_t<decltype(*p)>;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    void* q = nullptr;
+    AGZ_HIP(hipMalloc(&q, bytes));
+    AGZ_HIP(hipMemsetAsync(q, 0, bytes, stream_));
+    p = (T*)q;
+    bufs_.push_back(q);
+    state_bytes_ += bytes;
+  });
+  bcap_ = V_.games * V_.par;
+  d_x32_.alloc((size_t)bcap_ * V_.P * 32);
+  d_pi_.alloc((size_t)bcap_ * V_.A);
+  d_v_.alloc((size_t)bcap_);
+  V_.pi = d_pi_.p;
+  V_.v = d_v_.p;
+  s_iout_.alloc(4);
+  net_.reset(new Net(V_.N, cfg.tower_height, stream_));
+  // every slot idle-retired until start()
+  std::vector<GameState> gs(V_.games);
+  std::memset(gs.data(), 0, sizeof(GameState) * gs.size());
+  for (auto& g : gs) g.phase = G_RETIRED;
+  AGZ_HIP(hipMemcpyAsync(V_.gs, gs.data(), sizeof(GameState) * gs.size(), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+Engine::~Engine() {
+  (void)hipStreamSynchronize(stream_);
+  for (void* p : bufs_) (void)hipFree(p);
+  net_.reset();
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::sync() { AGZ_HIP(hipStreamSynchronize(stream_)); }
+
+void Engine::start(int64_t total_games) {
+  V_.total_games = total_games;
+  AGZ_HIP(hipMemsetAsync(V_.counters, 0, sizeof(unsigned long long) * CT_COUNT, stream_));
+  std::vector<GameState> gs(V_.games);
+  std::memset(gs.data(), 0, sizeof(GameState) * gs.size());
+  for (auto& g : gs) g.phase = G_IDLE;
+  AGZ_HIP(hipMemcpyAsync(V_.gs, gs.data(), sizeof(GameState) * gs.size(), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::step(int nsteps) {
+  AGZ_REQUIRE(!cfg_.external_network, AGZ_BAD_ARGUMENT,
+              "engine was created with external_network=1: use select/incorporate");
+  for (int s = 0; s < nsteps; ++s) {
+    hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream_, V_);
+    hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWave), 0, stream_, V_, 0, d_x32_.p, (float*)nullptr);
+    net_->forward(d_x32_.p, V_.batch_count, bcap_, d_pi_.p, d_v_.p);
+    hipLaunchKernelGGL(k_post, dim3(V_.games), dim3(kWave), 0, stream_, V_);
+  }
+  AGZ_HIP(hipGetLastError());
+}
+
+int Engine::select_external() {
+  hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream_, V_);
+  int32_t n = 0;
+  AGZ_HIP(hipMemcpyAsync(&n, V_.batch_count, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  external_batch_ = n;
+  return n;
+}
+
+void Engine::leaf_features_external(float* feats_out) {
+  const int B = external_batch_;
+  if (B <= 0) return;
+  d_whcn_.ensure((size_t)bcap_ * 17 * V_.P);
+  hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWave), 0, stream_, V_, 0, (float*)nullptr, d_whcn_.p);
+  AGZ_HIP(hipMemcpyAsync(feats_out, d_whcn_.p, sizeof(float) * (size_t)B * 17 * V_.P, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::incorporate_external(const float* pi, const float* v) {
+  const int B = external_batch_;
+  if (B > 0) {
+    AGZ_HIP(hipMemcpyAsync(d_pi_.p, pi, sizeof(float) * (size_t)B * V_.A, hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipMemcpyAsync(d_v_.p, v, sizeof(float) * (size_t)B, hipMemcpyHostToDevice, stream_));
+  }
+  hipLaunchKernelGGL(k_post, dim3(V_.games), dim3(kWave), 0, stream_, V_);
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  external_batch_ = 0;
+}
+
+void Engine::stats(agz_stats* out) {
+  unsigned long long c[CT_COUNT];
+  AGZ_HIP(hipMemcpyAsync(c, V_.counters, sizeof(c), hipMemcpyDeviceToHost, stream_));
+  std::vector<GameState> gs(V_.games);
+  AGZ_HIP(hipMemcpyAsync(gs.data(), V_.gs, sizeof(GameState) * gs.size(), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  std::memset(out, 0, sizeof(*out));
+  out->steps = (int64_t)c[CT_STEPS];
+  out->positions = (int64_t)c[CT_POSITIONS];
+  out->games_started = (int64_t)c[CT_STARTED];
+  out->games_finished = (int64_t)c[CT_FINISHED];
+  out->evals = (int64_t)c[CT_EVALS];
+  out->duplicate_evals = (int64_t)c[CT_DUP];
+  out->terminal_visits = (int64_t)c[CT_TERMINAL];
+  out->pool_exhausted = (int64_t)c[CT_POOL_EXHAUSTED];
+  out->resigned_games = (int64_t)c[CT_RESIGNED];
+  out->root_visits = (int64_t)c[CT_ROOTVISITS];
+  for (const auto& g : gs) {
+    out->nodes_in_use += g.nodes_used;
+    out->live_games += (g.phase != G_RETIRED && g.phase != G_IDLE);
+  }
+}
+
+// ---- records
+
+int64_t Engine::records_count() {
+  unsigned long long f = 0;
+  AGZ_HIP(hipMemcpyAsync(&f, V_.counters + CT_FINISHED, sizeof(f), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  return (int64_t)std::min<unsigned long long>(f, (unsigned long long)V_.fin_cap);
+}
+
+void Engine::record_header(int64_t k, agz_game_header* out) {
+  AGZ_REQUIRE(k >= 0 && k < records_count(), AGZ_BAD_ARGUMENT, "record %lld out of range", (long long)k);
+  AGZ_HIP(hipMemcpyAsync(out, V_.fin_hdr + k, sizeof(*out), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::record_game(int64_t k, int16_t* moves, float* pis, float* qs) {
+  agz_game_header h;
+  record_header(k, &h);
+  const size_t mgl = V_.max_game_length, nm = (size_t)h.num_moves;
+  if (nm == 0) return;
+  if (moves) AGZ_HIP(hipMemcpyAsync(moves, V_.fin_moves + k * mgl, sizeof(int16_t) * nm, hipMemcpyDeviceToHost, stream_));
+  if (qs) AGZ_HIP(hipMemcpyAsync(qs, V_.fin_q + k * mgl, sizeof(float) * nm, hipMemcpyDeviceToHost, stream_));
+  if (pis) AGZ_HIP(hipMemcpyAsync(pis, V_.fin_pi + k * mgl * V_.A, sizeof(float) * nm * V_.A, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+static size_t packed_record_bytes(const View& V, int nm) {
+  size_t b = sizeof(agz_game_header) + sizeof(int16_t) * (size_t)nm;
+  b = (b + 3) & ~(size_t)3;
+  b += sizeof(float) * (size_t)nm * V.A + sizeof(float) * (size_t)nm;
+  return (b + 7) & ~(size_t)7;
+}
+
+int64_t Engine::records_packed_size() {
+  const int64_t n = records_count();
+  std::vector<agz_game_header> h((size_t)n);
+  if (n) AGZ_HIP(hipMemcpy(h.data(), V_.fin_hdr, sizeof(agz_game_header) * (size_t)n, hipMemcpyDeviceToHost));
+  size_t total = 0;
+  for (auto& x : h) total += packed_record_bytes(V_, x.num_moves);
+  return (int64_t)total;
+}
+
+void Engine::records_export_packed(void* dst, int64_t capacity, bool is_device) {
+  const int64_t n = records_count();
+  std::vector<agz_game_header> h((size_t)n);
+  if (n) AGZ_HIP(hipMemcpy(h.data(), V_.fin_hdr, sizeof(agz_game_header) * (size_t)n, hipMemcpyDeviceToHost));
+  const size_t mgl = V_.max_game_length;
+  const hipMemcpyKind kd = is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  const hipMemcpyKind kh = is_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
+  size_t off = 0;
+  char* out = (char*)dst;
+  for (int64_t k = 0; k < n; ++k) {
+    const size_t nm = (size_t)h[k].num_moves, need = packed_record_bytes(V_, (int)nm);
+    AGZ_REQUIRE((int64_t)(off + need) <= capacity, AGZ_BAD_ARGUMENT, "export buffer too small");
+    size_t o = off;
+    AGZ_HIP(hipMemcpyAsync(out + o, &h[k], sizeof(agz_game_header), kh, stream_));
+    o += sizeof(agz_game_header);
+    if (nm) AGZ_HIP(hipMemcpyAsync(out + o, V_.fin_moves + k * mgl, sizeof(int16_t) * nm, kd, stream_));
+    o += sizeof(int16_t) * nm;
+    o = (o + 3) & ~(size_t)3;
+    if (nm) AGZ_HIP(hipMemcpyAsync(out + o, V_.fin_pi + k * mgl * V_.A, sizeof(float) * nm * V_.A, kd, stream_));
+    o += sizeof(float) * nm * V_.A;
+    if (nm) AGZ_HIP(hipMemcpyAsync(out + o, V_.fin_q + k * mgl, sizeof(float) * nm, kd, stream_));
+    off += need;
+  }
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::records_clear() {
+  AGZ_HIP(hipMemsetAsync(V_.counters + CT_FINISHED, 0, sizeof(unsigned long long), stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::record_features(int64_t k, float* out) {
+  agz_game_header h;
+  record_header(k, &h);
+  if (h.num_moves <= 0) return;
+  const size_t per = (size_t)17 * V_.P;
+  s_f32a_.ensure(per * (size_t)h.num_moves);
+  s_boards_.ensure((size_t)8 * V_.PP);
+  hipLaunchKernelGGL(k_replay_features, dim3(1), dim3(kWave), 0, stream_, V_,
+                     (const int16_t*)(V_.fin_moves + k * V_.max_game_length), h.num_moves, cfg_.komi, s_boards_.p,
+                     s_f32a_.p);
+  AGZ_HIP(hipMemcpyAsync(out, s_f32a_.p, sizeof(float) * per * (size_t)h.num_moves, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- network entry points
+
+void Engine::features(const int8_t* boards, const int8_t* deltas, const int32_t* ndeltas, const int8_t* to_play,
+                      int B, float* out) {
+  AGZ_REQUIRE(B >= 0, AGZ_BAD_ARGUMENT, "B < 0");
+  if (B == 0) return;
+  const size_t P = V_.P;
+  s_boards_.ensure((size_t)B * P);
+  s_deltas_.ensure((size_t)B * 7 * P);
+  s_i32a_.ensure(B);
+  s_tp_.ensure(B);
+  s_f32a_.ensure((size_t)B * 17 * P);
+  AGZ_HIP(hipMemcpyAsync(s_boards_.p, boards, (size_t)B * P, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_deltas_.p, deltas, (size_t)B * 7 * P, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i32a_.p, ndeltas, sizeof(int32_t) * B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_tp_.p, to_play, (size_t)B, hipMemcpyHostToDevice, stream_));
+  launch_features_from_deltas(s_boards_.p, s_deltas_.p, s_i32a_.p, s_tp_.p, B, V_.N, nullptr, s_f32a_.p, stream_);
+  AGZ_HIP(hipMemcpyAsync(out, s_f32a_.p, sizeof(float) * (size_t)B * 17 * P, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::net_forward_positions(const int8_t* boards, const int8_t* deltas, const int32_t* ndeltas,
+                                   const int8_t* to_play, int B, float* pi_out, float* v_out) {
+  AGZ_REQUIRE(B >= 0, AGZ_BAD_ARGUMENT, "B < 0");
+  if (B == 0) return;
+  const size_t P = V_.P;
+  s_boards_.ensure((size_t)B * P);
+  s_deltas_.ensure((size_t)B * 7 * P);
+  s_i32a_.ensure(B);
+  s_tp_.ensure(B);
+  d_count_.ensure(1);
+  s_f32a_.ensure((size_t)B * P * 32);
+  s_f32b_.ensure((size_t)B * (V_.A + 1));
+  AGZ_HIP(hipMemcpyAsync(s_boards_.p, boards, (size_t)B * P, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_deltas_.p, deltas, (size_t)B * 7 * P, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i32a_.p, ndeltas, sizeof(int32_t) * B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_tp_.p, to_play, (size_t)B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(d_count_.p, &B, sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+  launch_features_from_deltas(s_boards_.p, s_deltas_.p, s_i32a_.p, s_tp_.p, B, V_.N, s_f32a_.p, nullptr, stream_);
+  net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
+  AGZ_HIP(hipMemcpyAsync(pi_out, s_f32b_.p, sizeof(float) * (size_t)B * V_.A, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(v_out, s_f32b_.p + (size_t)B * V_.A, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::net_forward_features(const float* feats, int B, float* pi_out, float* v_out) {
+  AGZ_REQUIRE(B >= 0, AGZ_BAD_ARGUMENT, "B < 0");
+  if (B == 0) return;
+  const size_t P = V_.P;
+  d_whcn_.ensure((size_t)B * 17 * P);
+  d_count_.ensure(1);
+  s_f32a_.ensure((size_t)B * P * 32);
+  s_f32b_.ensure((size_t)B * (V_.A + 1));
+  AGZ_HIP(hipMemcpyAsync(d_whcn_.p, feats, sizeof(float) * (size_t)B * 17 * P, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(d_count_.p, &B, sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+  launch_whcn_to_x32(d_whcn_.p, B, V_.N, s_f32a_.p, stream_);
+  net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
+  AGZ_HIP(hipMemcpyAsync(pi_out, s_f32b_.p, sizeof(float) * (size_t)B * V_.A, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(v_out, s_f32b_.p + (size_t)B * V_.A, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+// random stone features (not zeros: DVFS makes zero-filled operands look faster than real data)
+void Engine::fill_synthetic_inputs(int B) {
+  const size_t P = V_.P;
+  std::vector<int8_t> boards((size_t)B * P), deltas((size_t)B * 7 * P, 0), tp(B);
+  std::vector<int32_t> nd(B, 0);
+  uint64_t s = 0x1234567ull;
+  for (auto& x : boards) {
+    s = agz_mix64(s + 0x9E3779B97F4A7C15ull);
+    const int r = (int)(s % 3);
+    x = (int8_t)(r == 2 ? -1 : r);
+  }
+  for (int b = 0; b < B; ++b) tp[b] = (b & 1) ? -1 : 1;
+  s_boards_.ensure(boards.size());
+  s_deltas_.ensure(deltas.size());
+  s_i32a_.ensure(B);
+  s_tp_.ensure(B);
+  d_count_.ensure(1);
+  s_f32a_.ensure((size_t)B * P * 32);
+  s_f32b_.ensure((size_t)B * (V_.A + 1));
+  AGZ_HIP(hipMemcpyAsync(s_boards_.p, boards.data(), boards.size(), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_deltas_.p, deltas.data(), deltas.size(), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i32a_.p, nd.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_tp_.p, tp.data(), (size_t)B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(d_count_.p, &B, sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+  launch_features_from_deltas(s_boards_.p, s_deltas_.p, s_i32a_.p, s_tp_.p, B, V_.N, s_f32a_.p, nullptr, stream_);
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+float Engine::time_forward(int B, int iters) {
+  AGZ_REQUIRE(B > 0 && iters > 0, AGZ_BAD_ARGUMENT, "B and iters must be positive");
+  fill_synthetic_inputs(B);
+  net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);   // warm-up
+  hipEvent_t e0, e1;
+  AGZ_HIP(hipEventCreate(&e0));
+  AGZ_HIP(hipEventCreate(&e1));
+  AGZ_HIP(hipEventRecord(e0, stream_));
+  for (int i = 0; i < iters; ++i) net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
+  AGZ_HIP(hipEventRecord(e1, stream_));
+  AGZ_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  AGZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ms / (float)iters;
+}
+
+float Engine::time_conv(int B, int iters) {
+  AGZ_REQUIRE(B > 0 && iters > 0, AGZ_BAD_ARGUMENT, "B and iters must be positive");
+  fill_synthetic_inputs(B);
+  // one forward leaves real (post-ReLU, mixed-sign-weight) activations in the tower buffers
+  net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
+  net_->launch_tower_conv_once(d_count_.p, B);
+  hipEvent_t e0, e1;
+  AGZ_HIP(hipEventCreate(&e0));
+  AGZ_HIP(hipEventCreate(&e1));
+  AGZ_HIP(hipEventRecord(e0, stream_));
+  for (int i = 0; i < iters; ++i) net_->launch_tower_conv_once(d_count_.p, B);
+  AGZ_HIP(hipEventRecord(e1, stream_));
+  AGZ_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  AGZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ms / (float)iters;
+}
+
+void Engine::debug_draws(uint64_t seed, uint64_t game, uint32_t move, int n, double alpha, double* out) {
+  if (n <= 0) return;
+  s_f64_.ensure(n);
+  hipLaunchKernelGGL(k_debug_draws, dim3(ceil_div(n, 64)), dim3(64), 0, stream_, seed, game, move, n, alpha, s_f64_.p);
+  AGZ_HIP(hipMemcpyAsync(out, s_f64_.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::debug_math(int op, const double* x, const double* y, int n, double* out) {
+  if (n <= 0) return;
+  s_f64_.ensure((size_t)3 * n);
+  AGZ_HIP(hipMemcpyAsync(s_f64_.p, x, sizeof(double) * n, hipMemcpyHostToDevice, stream_));
+  if (y) AGZ_HIP(hipMemcpyAsync(s_f64_.p + n, y, sizeof(double) * n, hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_debug_math, dim3(ceil_div(n, 64)), dim3(64), 0, stream_, V_, op, (const double*)s_f64_.p,
+                     (const double*)(s_f64_.p + n), n, s_f64_.p + 2 * (size_t)n);
+  AGZ_HIP(hipMemcpyAsync(out, s_f64_.p + 2 * (size_t)n, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- Go rules
+
+void Engine::go_play(const int8_t* boards, const int8_t* to_play, const int32_t* ko, const int32_t* moves, int B,
+                     int8_t* boards_out, int32_t* ko_out, int32_t* ncap_out, int32_t* status_out) {
+  if (B <= 0) return;
+  const size_t P = V_.P;
+  s_boards_.ensure((size_t)B * P);
+  s_boards_out_.ensure((size_t)B * P);
+  s_tp_.ensure(B);
+  s_i32a_.ensure(B); s_i32b_.ensure(B); s_i32c_.ensure((size_t)3 * B);
+  AGZ_HIP(hipMemcpyAsync(s_boards_.p, boards, (size_t)B * P, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_tp_.p, to_play, (size_t)B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i32a_.p, ko, sizeof(int32_t) * B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i32b_.p, moves, sizeof(int32_t) * B, hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_go_play, dim3(B), dim3(kWave), 0, stream_, V_, (const int8_t*)s_boards_.p,
+                     (const int8_t*)s_tp_.p, (const int32_t*)s_i32a_.p, (const int32_t*)s_i32b_.p, B,
+                     s_boards_out_.p, s_i32c_.p, s_i32c_.p + B, s_i32c_.p + 2 * (size_t)B);
+  AGZ_HIP(hipMemcpyAsync(boards_out, s_boards_out_.p, (size_t)B * P, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(ko_out, s_i32c_.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(ncap_out, s_i32c_.p + B, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(status_out, s_i32c_.p + 2 * (size_t)B, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::go_legal(const int8_t* boards, const int8_t* to_play, const int32_t* ko, int B, int8_t* out) {
+  if (B <= 0) return;
+  const size_t P = V_.P;
+  s_boards_.ensure((size_t)B * P);
+  s_tp_.ensure(B);
+  s_i32a_.ensure(B);
+  s_legal_.ensure((size_t)B * V_.A);
+  AGZ_HIP(hipMemcpyAsync(s_boards_.p, boards, (size_t)B * P, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_tp_.p, to_play, (size_t)B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i32a_.p, ko, sizeof(int32_t) * B, hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_go_legal, dim3(B), dim3(kWave), 0, stream_, V_, (const int8_t*)s_boards_.p,
+                     (const int8_t*)s_tp_.p, (const int32_t*)s_i32a_.p, B, s_legal_.p);
+  AGZ_HIP(hipMemcpyAsync(out, s_legal_.p, (size_t)B * V_.A, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::go_score(const int8_t* boards, const float* komi, int B, float* out) {
+  if (B <= 0) return;
+  const size_t P = V_.P;
+  s_boards_.ensure((size_t)B * P);
+  s_f32a_.ensure((size_t)2 * B);
+  AGZ_HIP(hipMemcpyAsync(s_boards_.p, boards, (size_t)B * P, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_f32a_.p, komi, sizeof(float) * B, hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_go_score, dim3(B), dim3(kWave), 0, stream_, V_, (const int8_t*)s_boards_.p,
+                     (const float*)s_f32a_.p, B, s_f32a_.p + B);
+  AGZ_HIP(hipMemcpyAsync(out, s_f32a_.p + B, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- single-tree compat
+
+void Engine::check_game(int g) const {
+  AGZ_REQUIRE(g >= 0 && g < V_.games, AGZ_BAD_ARGUMENT, "game slot %d of %d", g, V_.games);
+}
+void Engine::check_node(int g, int node) const {
+  check_game(g);
+  AGZ_REQUIRE(node >= 0 && node < V_.cap, AGZ_BAD_ARGUMENT, "node %d of %d", node, V_.cap);
+}
+
+int Engine::tree_op(TreeArgs& T, int32_t* r0) {
+  check_game(T.g);
+  // stage host-side inputs
+  if (T.probs) {
+    s_f32a_.ensure(V_.A);
+    AGZ_HIP(hipMemcpyAsync(s_f32a_.p, T.probs, sizeof(float) * V_.A, hipMemcpyHostToDevice, stream_));
+    T.probs = s_f32a_.p;
+  }
+  if (T.board) {
+    s_boards_.ensure(V_.P);
+    AGZ_HIP(hipMemcpyAsync(s_boards_.p, T.board, (size_t)V_.P, hipMemcpyHostToDevice, stream_));
+    T.board = s_boards_.p;
+  }
+  if (T.history && T.info.history_len > 0) {
+    s_deltas_.ensure((size_t)7 * V_.P);
+    AGZ_HIP(hipMemcpyAsync(s_deltas_.p, T.history, (size_t)std::min(T.info.history_len, 7) * V_.P,
+                           hipMemcpyHostToDevice, stream_));
+    T.history = s_deltas_.p;
+  }
+  double* host_dout = T.dout;
+  if (T.dout) {
+    s_f64_.ensure(V_.A);
+    T.dout = s_f64_.p;
+  }
+  T.iout = s_iout_.p;
+  hipLaunchKernelGGL(k_tree_op, dim3(1), dim3(kWave), 0, stream_, V_, T);
+  int32_t iout[4] = {0, 0, 0, 0};
+  AGZ_HIP(hipMemcpyAsync(iout, s_iout_.p, sizeof(iout), hipMemcpyDeviceToHost, stream_));
+  if (host_dout) AGZ_HIP(hipMemcpyAsync(host_dout, s_f64_.p, sizeof(double) * V_.A, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  if (r0) *r0 = iout[1];
+  return iout[0];
+}
+
+// tree_search!(player, parallel_readouts) on slot g, split at the network call so that any
+// callable can stand in for the network (MCTSPlayer.network is duck-typed, mcts_play.jl:5,89)
+int Engine::tree_search_select(int g, int par, int* nleaves) {
+  check_game(g);
+  AGZ_REQUIRE(par >= 1 && par <= V_.par, AGZ_BAD_ARGUMENT,
+              "parallel_readouts %d exceeds the engine's configured %d", par, V_.par);
+  TreeArgs T;
+  std::memset(&T, 0, sizeof(T));
+  T.op = TOP_SEARCH_SELECT; T.g = g; T.par = par;
+  int32_t n = 0;
+  const int st = tree_op(T, &n);
+  *nleaves = n;
+  tree_batch_ = n;
+  return st;
+}
+
+void Engine::tree_leaf_features(int g, float* feats_out) {
+  check_game(g);
+  if (tree_batch_ <= 0) return;
+  d_whcn_.ensure((size_t)bcap_ * 17 * V_.P);
+  hipLaunchKernelGGL(k_leaf_features, dim3(V_.par), dim3(kWave), 0, stream_, V_, g, (float*)nullptr, d_whcn_.p);
+  AGZ_HIP(hipMemcpyAsync(feats_out, d_whcn_.p, sizeof(float) * (size_t)tree_batch_ * 17 * V_.P,
+                         hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+int Engine::tree_search_incorporate(int g, const float* pi, const float* v) {
+  check_game(g);
+  const int n = tree_batch_;
+  if (n > 0) {
+    if (pi && v) {
+      AGZ_HIP(hipMemcpyAsync(d_pi_.p, pi, sizeof(float) * (size_t)n * V_.A, hipMemcpyHostToDevice, stream_));
+      AGZ_HIP(hipMemcpyAsync(d_v_.p, v, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, stream_));
+    } else {
+      d_count_.ensure(1);
+      AGZ_HIP(hipMemcpyAsync(d_count_.p, &n, sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+      hipLaunchKernelGGL(k_leaf_features, dim3(V_.par), dim3(kWave), 0, stream_, V_, g, d_x32_.p, (float*)nullptr);
+      net_->forward(d_x32_.p, d_count_.p, std::min(bcap_, V_.par), d_pi_.p, d_v_.p);
+    }
+  }
+  TreeArgs T;
+  std::memset(&T, 0, sizeof(T));
+  T.op = TOP_SEARCH_POST; T.g = g;
+  tree_batch_ = 0;
+  return tree_op(T, nullptr);
+}
+
+void Engine::game_state(int g, GameState* out) {
+  check_game(g);
+  AGZ_HIP(hipMemcpyAsync(out, V_.gs + g, sizeof(GameState), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::game_patch(int g, const GameState& s) {
+  check_game(g);
+  AGZ_HIP(hipMemcpyAsync(V_.gs + g, &s, sizeof(GameState), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::node_meta(int g, int node, NodeMeta* out) {
+  check_node(g, node);
+  AGZ_HIP(hipMemcpyAsync(out, V_.meta + node_index(V_, g, node), sizeof(NodeMeta), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::node_meta_set(int g, int node, const NodeMeta& m) {
+  check_node(g, node);
+  AGZ_HIP(hipMemcpyAsync(V_.meta + node_index(V_, g, node), &m, sizeof(NodeMeta), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+static float* row_base(const View& V, int field) {
+  return field == AGZ_F_CHILD_N ? V.childN : field == AGZ_F_CHILD_W ? V.childW : V.childP;
+}
+void Engine::node_row_get(int g, int node, int field, float* out) {
+  check_node(g, node);
+  AGZ_REQUIRE(field >= 0 && field <= 2, AGZ_BAD_ARGUMENT, "field %d", field);
+  AGZ_HIP(hipMemcpyAsync(out, row_base(V_, field) + node_index(V_, g, node) * V_.AP, sizeof(float) * V_.A,
+                         hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::node_row_set(int g, int node, int field, const float* in) {
+  check_node(g, node);
+  AGZ_REQUIRE(field >= 0 && field <= 2, AGZ_BAD_ARGUMENT, "field %d", field);
+  AGZ_HIP(hipMemcpyAsync(row_base(V_, field) + node_index(V_, g, node) * V_.AP, in, sizeof(float) * V_.A,
+                         hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::node_children(int g, int node, int32_t* out) {
+  check_node(g, node);
+  AGZ_HIP(hipMemcpyAsync(out, V_.child + node_index(V_, g, node) * V_.AP, sizeof(int32_t) * V_.A,
+                         hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::node_board(int g, int node, int8_t* out) {
+  check_node(g, node);
+  AGZ_HIP(hipMemcpyAsync(out, V_.board + node_index(V_, g, node) * V_.PP, (size_t)V_.P, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+float Engine::node_stat(int g, int node, int which) {
+  NodeMeta m;
+  node_meta(g, node, &m);
+  float v = 0.f;
+  const float* src;
+  if (m.parent < 0) {
+    src = which == 0 ? &V_.gs[g].rootN : &V_.gs[g].rootW;
+  } else {
+    src = (which == 0 ? V_.childN : V_.childW) + node_index(V_, g, m.parent) * V_.AP + m.fmove;
+  }
+  AGZ_HIP(hipMemcpyAsync(&v, src, sizeof(float), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  return v;
+}
+void Engine::node_set_N(int g, int node, float v) {
+  NodeMeta m;
+  node_meta(g, node, &m);
+  float* dst = m.parent < 0 ? &V_.gs[g].rootN : V_.childN + node_index(V_, g, m.parent) * V_.AP + m.fmove;
+  AGZ_HIP(hipMemcpyAsync(dst, &v, sizeof(float), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+}  // namespace agz

@@ -26,6 +26,7 @@ struct DenseHost {
 class Net {
  public:
   Net(int N, int tower, hipStream_t stream);
+  ~Net();
   int N() const { return N_; }
   int P() const { return P_; }
   int A() const { return A_; }
@@ -42,6 +43,10 @@ class Net {
   void forward(const float* d_x32, const int* d_count, int bcap, float* d_pi, float* d_v);
   // one tower conv launch on resident synthetic activations (for roofline timing)
   void launch_tower_conv_once(const int* d_count, int bcap);
+
+  // HIP-event timing of every tower-conv launch inside forward() (bench.py roofline leg)
+  void profile_enable(bool on);
+  void profile_read(double* total_ms, double* total_flop, int64_t* launches);
 
   double flops_per_eval() const;         // BASELINE.md F_eval
   double conv_flops_per_launch(int B) const { return 2.0 * B * P_ * 9.0 * kC * kC; }
@@ -68,6 +73,13 @@ class Net {
   // workspace
   int bcap_ = 0;
   DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
+  // profiling
+  bool prof_on_ = false;
+  std::vector<hipEvent_t> prof_ev_;
+  std::vector<int> prof_fwd_of_;
+  int32_t* prof_counts_ = nullptr;   // pinned host
+  int prof_n_ = 0, prof_fwd_ = 0;
+  static constexpr int kProfMax = 4096;
 };
 
 // feature extraction entry points (features.jl:3-26) from the reference's own position format

@@ -522,17 +522,25 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
   reserve(bcap);
   const int grid = conv_grid(bcap, P_);
   float *a = d_a_.p, *b = d_b_.p, *t = d_t_.p;
+  if (prof_on_ && prof_fwd_ < kProfMax)
+    (void)hipMemcpyAsync(&prof_counts_[prof_fwd_], d_count, sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
   hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad>), dim3(grid), dim3(256), 0, stream_, d_x32, d_wstem_.p,
                      d_scale_.p, d_shift_.p, (const float*)nullptr, a, d_count, N_, 1);
   const size_t per = (size_t)kC * 9 * kC;
   for (int blk = 0; blk < tower_; ++blk) {
     const int l1 = 2 * blk, l2 = 2 * blk + 1;
+    const bool p1 = prof_on_ && prof_n_ < kProfMax;
+    if (p1) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
     hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)a,
                        d_wtower_.p + per * l1, d_scale_.p + (size_t)(l1 + 1) * kC,
                        d_shift_.p + (size_t)(l1 + 1) * kC, (const float*)nullptr, t, d_count, N_, 1);
+    if (p1) { (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_); prof_fwd_of_[prof_n_++] = prof_fwd_; }
+    const bool p2 = prof_on_ && prof_n_ < kProfMax;
+    if (p2) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
     hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)t,
                        d_wtower_.p + per * l2, d_scale_.p + (size_t)(l2 + 1) * kC,
                        d_shift_.p + (size_t)(l2 + 1) * kC, (const float*)a, b, d_count, N_, 1);
+    if (p2) { (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_); prof_fwd_of_[prof_n_++] = prof_fwd_; }
     std::swap(a, b);
   }
   const int hgrid = std::min(ceil_div((long)bcap * P_, 4), 256 * 16);
@@ -542,7 +550,40 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
   hipLaunchKernelGGL(k_head_fc, dim3(bcap), dim3(256), smem, stream_, (const float*)d_vh_.p,
                      (const float*)d_ph_.p, d_vfc1w_.p, d_vfc1b_.p, d_vfc2w_.p, d_vfc2b_.p, d_pfcw_.p,
                      d_pfcb_.p, d_pi, d_v, d_count, P_, A_);
+  if (prof_on_ && prof_fwd_ < kProfMax) prof_fwd_++;
   AGZ_HIP(hipGetLastError());
+}
+
+Net::~Net() {
+  for (auto e : prof_ev_) (void)hipEventDestroy(e);
+  if (prof_counts_) (void)hipHostFree(prof_counts_);
+}
+
+void Net::profile_enable(bool on) {
+  if (on && prof_ev_.empty()) {
+    prof_ev_.resize(2 * kProfMax);
+    for (auto& e : prof_ev_) AGZ_HIP(hipEventCreate(&e));
+    prof_fwd_of_.assign(kProfMax, 0);
+    AGZ_HIP(hipHostMalloc((void**)&prof_counts_, sizeof(int32_t) * kProfMax, hipHostMallocDefault));
+  }
+  prof_on_ = on;
+  prof_n_ = 0;
+  prof_fwd_ = 0;
+}
+
+void Net::profile_read(double* total_ms, double* total_flop, int64_t* launches) {
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  double ms = 0.0, fl = 0.0;
+  for (int i = 0; i < prof_n_; ++i) {
+    float t = 0.f;
+    AGZ_HIP(hipEventElapsedTime(&t, prof_ev_[2 * i], prof_ev_[2 * i + 1]));
+    ms += t;
+    const int f = prof_fwd_of_[i];
+    fl += conv_flops_per_launch(f < kProfMax ? prof_counts_[f] : 0);
+  }
+  *total_ms = ms;
+  *total_flop = fl;
+  *launches = prof_n_;
 }
 
 void Net::launch_tower_conv_once(const int* d_count, int bcap) {

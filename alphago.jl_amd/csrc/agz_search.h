@@ -713,6 +713,7 @@ AGZ_FN void game_start(W& w, const View& V, Scratch& S, int g, uint64_t game_id)
     G.rootN = 0.f; G.rootW = 0.f; G.target = 0.f; G.komi = V.komi;
     G.sel = 0; G.move_count = 0; G.nqs = 0; G.hist_len = 0;
     G.free_top = V.cap; G.nleaves = 0; G.err = 0; G.result = 0; G.was_resign = 0; G.nodes_used = 0;
+    G.short_first = 0;
     G.phase = G_INIT;
   }
   w.sync();
@@ -726,8 +727,11 @@ AGZ_FN void game_start(W& w, const View& V, Scratch& S, int g, uint64_t game_id)
   if (w.leader()) G.root = id;
   w.sync();
   w.count(&V.counters[CT_STARTED], 1);
-  // bench-only: a random opening prefix so that concurrent games are at mixed stages
+  // bench-only: a random opening prefix so that concurrent games are at mixed stages, and a
+  // shortened first search so that they are also at mixed phases of their readout budget
   if (V.stagger > 0) {
+    if (w.leader()) G.short_first = 1;
+    w.sync();
     const int want = (int)agz_index(agz_draw_u64(V.seed, game_id, 0, AGZ_SITE_STAGGER, 0), (uint32_t)V.stagger + 1u);
     for (int t = 0; t < want; ++t) {
       const long ni = node_index(V, g, G.root);
@@ -809,7 +813,10 @@ AGZ_FN void game_move_phase(W& w, const View& V, Scratch& S, int g) {
   reroot(w, V, S, g, a, child);
   if (w.leader()) { G.move_count = k + 1; G.nqs = k + 1; }
   w.sync();
-  w.count(&V.counters[CT_POSITIONS], 1);
+  if (!G.short_first) w.count(&V.counters[CT_POSITIONS], 1);
+  w.sync();
+  if (w.leader()) G.short_first = 0;
+  w.sync();
   if (node_is_done(V, g, child)) {
     load_board(w, V, S, node_index(V, g, child));
     const float sc = area_score(w, V, S, G.komi);
@@ -868,7 +875,7 @@ AGZ_FN void game_select_phase(W& w, const View& V, Scratch& S, int g, int par) {
   w.sync();
   w.count(&V.counters[CT_TERMINAL], (unsigned long long)terminal);
   w.count(&V.counters[CT_EVALS], (unsigned long long)nleaves);
-  (void)n_before;
+  w.count(&V.counters[CT_ROOTVISITS], (unsigned long long)(G.rootN - n_before));
 }
 
 // Phase A+B of a self-play step for game slot g: lifecycle, per-move phase, select.
@@ -926,7 +933,15 @@ AGZ_FN void game_post(W& w, const View& V, Scratch& S, int g) {
   (void)n_before;
   if (G.phase == G_INIT_WAIT) {
     inject_noise(w, V, S, g, G.root);
-    if (w.leader()) { G.target = G.rootN + (float)V.R; G.phase = G_SEARCH; }
+    if (w.leader()) {
+      float budget = (float)V.R;
+      if (G.short_first) {
+        const double u = agz_u01(agz_draw_u64(V.seed, G.game_id, 0, AGZ_SITE_STAGGER, 1000000u));
+        budget = (float)(1 + (int)(u * (double)(V.R - 1)));
+      }
+      G.target = G.rootN + budget;
+      G.phase = G_SEARCH;
+    }
   }
   if (w.leader()) G.nleaves = 0;
   w.sync();

@@ -55,7 +55,8 @@ struct GameState {
   int32_t result;
   int32_t was_resign;
   int32_t nodes_used;
-  int32_t pad[2];
+  int32_t short_first;       // bench stagger: the first search of this game has a shortened budget
+  int32_t pad;
 };
 
 enum Counter : int {

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play positions/sec of the MI355X-native hot path (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): GoEnv(9), tower_height=10, 400 readouts, 1024 concurrent
+self-play games per GPU, synthetic Flux-default-equivalent weights (random init from the draw
+stream), exact-f32 MFMA network.  One "step" = one tree_search! round for every live game: select
+up to 8 leaves per game -> 17-plane features -> ResNet forward on the coalesced batch (<= 8192
+positions) -> expand / back up, plus the per-move phase (resign check, pick, play, re-root, noise)
+for the games whose 400-readout budget is spent.  A "position" = one self-play move that received
+its full 400 readouts inside the run.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  value = positions played by all ranks / max-over-ranks time of
+exactly K steps bracketed by barrier + device sync.  Extra objects:
+  roofline      the dominant kernel (3x3 256->256 conv, v_mfma_f32_32x32x2_f32): algorithmic
+                TFLOP/s from HIP events around every tower-conv launch of the timed region
+  cpu_baseline  the CPU oracle (a port of the reference algorithm in the reference's execution
+                shape: one game at a time, batches of 8) timed on this host, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table (f32-in MFMA = f32 vector peak)
+
+
+def f_eval(N, t):
+    """algorithmic FLOP per network evaluation"""
+    P = N * N
+    return 2.0 * P * (9 * 17 * 256 + t * 2 * 9 * 256 * 256) + 2.0 * P * 256 * 3 + 2.0 * (2 * P * (P + 1) + P * 256 + 256)
+
+
+def cpu_baseline(N, tower, readouts, seconds):
+    """oracle selfplay on the host cores; returns the cpu_baseline object"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+
+    import numpy as np
+    import orc
+
+    L = orc.lib()
+    cores = os.cpu_count() or 1
+    L.or_set_num_threads(cores)
+    net = L.or_net_new(N, tower)
+    L.or_net_init_synthetic(net, 0)
+    A = N * N + 1
+    # calibrate on one batch-of-8 forward
+    x = np.zeros((8, 17 * N * N), np.float32)
+    pi = np.zeros((8, A), np.float32)
+    v = np.zeros(8, np.float32)
+    L.or_net_forward_feats(net, orc.fptr(x), 8, orc.fptr(pi), orc.fptr(v), 32)
+    t0 = time.perf_counter()
+    L.or_net_forward_feats(net, orc.fptr(x), 8, orc.fptr(pi), orc.fptr(v), 32)
+    t8 = time.perf_counter() - t0
+    per_move = t8 * (readouts / 8.0 + 1.0)
+    moves = int(max(1, min(8, round(seconds / max(per_move, 1e-6)))))
+    cb = orc.NET_FN(lambda ctx, pos, B, ppi, pv: L.or_net_callable(net, pos, B, ppi, pv))
+    t0 = time.perf_counter()
+    p = L.or_selfplay(N, cb, None, readouts, 1, 0, moves)
+    dt = time.perf_counter() - t0
+    played = L.or_player_num_moves(p)
+    evals = L.or_player_evals(p)
+    L.or_player_free(p)
+    L.or_net_free(net)
+    return {
+        "value": played / dt, "unit": "positions/s", "cores": cores, "kind": "port",
+        "sample": f"first {played} moves of one self-play game (GoEnv({N}), tower {tower}, {readouts} readouts, "
+                  f"batches of 8, fp32 C network with OpenMP on {cores} threads), {evals} evals in {dt:.1f} s",
+        "note": "reference (Julia/Flux) is not runnable here: no julia binary; CPU restatement timed",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--board", type=int, default=9)
+    ap.add_argument("--tower", type=int, default=10)
+    ap.add_argument("--readouts", type=int, default=400)
+    ap.add_argument("--games", type=int, default=1024, help="concurrent games per GPU")
+    ap.add_argument("--stagger", type=int, default=60, help="random opening prefix (moves) so games are at mixed stages")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import alphago_jl_amd as ag
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N, tower, R = args.board, args.tower, args.readouts
+    eng = ag.Engine(board_size=N, tower_height=tower, games=args.games, num_readouts=R, parallel_readouts=8,
+                    seed=1, game_id_base=rank, game_id_stride=world, device=local_rank,
+                    stagger_moves=args.stagger)
+    eng.init_synthetic(0)
+    eng.start(0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    eng.step(args.warmup)
+    eng.sync()
+    s0 = eng.stats()
+    eng.profile_conv(True)
+    barrier()
+    t0 = time.perf_counter()
+    eng.step(args.steps)
+    eng.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    conv_ms, conv_flop, conv_n = eng.profile_conv_read()
+    eng.profile_conv(False)
+    s1 = eng.stats()
+
+    elapsed = t1 - t0
+    d = {k: s1[k] - s0[k] for k in ("positions", "evals", "duplicate_evals", "terminal_visits", "root_visits",
+                                    "games_finished", "steps")}
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([d["positions"], d["evals"], d["root_visits"], d["games_finished"]], dtype=torch.float64,
+                         device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        d["positions"], d["evals"], d["root_visits"], d["games_finished"] = [float(x) for x in c.tolist()]
+    if s1["pool_exhausted"]:
+        raise SystemExit("node pool exhausted during the benchmark: results invalid")
+
+    if rank == 0:
+        value = d["positions"] / elapsed
+        fpos = R * f_eval(N, tower)
+        out = {
+            "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)",
+            "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"GoEnv({N}), tower_height={tower}, {R} readouts, {args.games} concurrent games per GPU, "
+                            f"8 leaves per game per step (batch <= {8 * args.games} positions)",
+                "games_per_gpu": args.games, "parallel_readouts": 8, "stagger_moves": args.stagger,
+                "weights": "synthetic glorot-uniform (seed 0), BN identity", "parallelism": f"games sharded x{world}",
+            },
+            "positions": d["positions"], "evals": d["evals"],
+            "evals_per_position": d["evals"] / max(d["positions"], 1),
+            "readout_positions_per_s": d["root_visits"] / R / elapsed,
+            "games_finished": d["games_finished"],
+            "end_to_end_mfma_frac": value * fpos / (world * PEAK_F32_MFMA_TFLOPS * 1e12),
+            "roofline": {
+                "bound": "mfma", "kernel": "k_conv3x3_mfma<256> (3x3 256->256 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                "achieved": conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": (conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
+                "traffic": None, "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
+                "flop_per_launch_avg": conv_flop / max(conv_n, 1),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, tower, R, args.cpu_baseline_seconds)
+            except Exception as e:  # the baseline leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,13 @@ agz_status agz_net_time_forward(agz_engine* e, int32_t B, int32_t iters, float* 
 /* average duration (ms) of the dominant 3x3 256->256 conv launch over the same kind of run */
 agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_out);
 
+/* HIP-event timing of every 3x3 256->256 tower-conv launch issued by subsequent steps /
+ * forwards (up to 4096 launches), on the engine's own stream.  read() synchronises and returns
+ * the summed launch time, the summed ALGORITHMIC flops (2 * rows * 9 * 256 * 256 with the rows
+ * each launch actually processed) and the launch count. */
+agz_status agz_profile_conv_enable(agz_engine* e, int32_t on);
+agz_status agz_profile_conv_read(agz_engine* e, double* total_ms, double* total_flop, int64_t* launches);
+
 /* ---------------------------------------------------------------- Go rules (batched) --- */
 /* play_move!(pos, c), board.jl:451-509 / pass_move! :426-440.  In/out SoA per position:
  * boards int8[B][N*N], to_play int8[B], ko int32[B] (-1 = none), moves int32[B].
@@ -217,6 +224,12 @@ agz_status agz_tree_inject_noise(agz_engine* e, int32_t g, int32_t node);
 /* tree_search!(player, parallel_readouts): select phase then (with an internal network) the
  * evaluation and incorporate phases; returns the number of leaves */
 agz_status agz_tree_search(agz_engine* e, int32_t g, int32_t parallel_readouts, int32_t* nleaves_out);
+/* the same split at the network call, for a caller-supplied network (DummyNet, a Flux model):
+ * select -> read the leaves' feature tensor (N x N x 17 x nleaves) -> hand back pi (A x nleaves)
+ * and v (nleaves); pi == NULL makes the engine evaluate the leaves with its own network */
+agz_status agz_tree_search_select(agz_engine* e, int32_t g, int32_t parallel_readouts, int32_t* nleaves_out);
+agz_status agz_tree_leaf_features(agz_engine* e, int32_t g, float* feats_out);
+agz_status agz_tree_search_incorporate(agz_engine* e, int32_t g, const float* pi, const float* v);
 agz_status agz_tree_pick_move(agz_engine* e, int32_t g, int32_t* a_out);
 agz_status agz_tree_play_move(agz_engine* e, int32_t g, int32_t a, int32_t* ok_out);
 agz_status agz_tree_should_resign(agz_engine* e, int32_t g, int32_t* out);
@@ -240,6 +253,17 @@ agz_status agz_tree_node_children(agz_engine* e, int32_t g, int32_t node, int32_
 agz_status agz_tree_node_board(agz_engine* e, int32_t g, int32_t node, int8_t* out /* [N*N] */);
 agz_status agz_tree_pending_vlosses(agz_engine* e, int32_t g, int32_t* out);
 agz_status agz_tree_set_draw(agz_engine* e, int32_t g, uint64_t game_id, uint32_t sel);
+
+/* ---------------------------------------------------------------- diagnostics ----------- */
+/* Evaluate the draw stream (include/agz_draws.h) ON THE DEVICE so tests can check that gfx950
+ * and the host produce bit-identical draws: gamma_out[a] = a-th un-normalised Dirichlet
+ * component for (seed, game, move). */
+agz_status agz_debug_draws(agz_engine* e, uint64_t seed, uint64_t game, uint32_t move, int32_t n,
+                           double alpha, double* gamma_out);
+/* op 0: agz_log(x) 1: agz_exp(x) 2: agz_pow(x, 0.98) 3: (double)sqrtf((float)x)
+ * 4: (double)((float)x / (float)y) 5: PUCT score of (W=x, N=y, P=0.25, to_play=-1, N_node=y+7) */
+agz_status agz_debug_math(agz_engine* e, int32_t op, const double* x, const double* y, int32_t n,
+                          double* out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,93 @@
+"""HIP network (features + MFMA tower + heads, through the C ABI) against the oracle.
+Tolerance: |d pi|, |d v| <= 1e-4 versus the float64 oracle (BASELINE.json north_star); feature
+planes are integer-valued and must match exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import alphago_jl_amd as ag
+import orc
+from gpu_common import copy_weights_from_oracle, pos_soa
+from test_hostsim_go import random_positions
+from test_oracle_nn import randomize_bn
+
+pytestmark = pytest.mark.gpu
+L = orc.lib()
+TOL = 1e-4
+
+
+def oracle_forward64(onet, feats, A):
+    B = feats.shape[0]
+    pi = np.zeros((B, A))
+    v = np.zeros(B)
+    x = feats.astype(np.float64)
+    L.or_net_forward_feats_f64(onet, x.ctypes.data_as(C.POINTER(C.c_double)), B,
+                               pi.ctypes.data_as(C.POINTER(C.c_double)), v.ctypes.data_as(C.POINTER(C.c_double)))
+    return pi, v
+
+
+@pytest.mark.parametrize("N", [5, 9, 19])
+def test_features_exact(N):
+    positions = random_positions(N, 6, 60, seed=N)[::3]
+    eng = ag.Engine(board_size=N, games=1, tower_height=0, num_readouts=8, max_nodes_per_game=16)
+    got = eng.features(*pos_soa(positions))
+    for b, p in enumerate(positions):
+        assert (got[b].reshape(17, N * N) == orc.feats(p)).all(), b
+    eng.close()
+
+
+@pytest.mark.parametrize("N,tower,B", [(5, 1, 7), (9, 2, 37), (9, 10, 16), (19, 3, 5)])
+def test_forward_matches_oracle(N, tower, B):
+    A = N * N + 1
+    rng = np.random.RandomState(N + tower)
+    onet = L.or_net_new(N, tower)
+    L.or_net_init_synthetic(onet, 3)
+    randomize_bn(onet, list(range(0, 1 + 2 * tower)) + [orc.L_VALUE_CONV, orc.L_POLICY_CONV], rng)
+    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    copy_weights_from_oracle(eng, onet, tower)
+    positions = random_positions(N, 4, 80, seed=7)
+    positions = [positions[i] for i in rng.choice(len(positions), B, replace=False)]
+    feats = np.stack([orc.feats(p).reshape(-1) for p in positions])
+    pi64, v64 = oracle_forward64(onet, feats, A)
+    gpi, gv = eng.forward(*pos_soa(positions))
+    assert np.abs(gpi - pi64).max() <= TOL, np.abs(gpi - pi64).max()
+    assert np.abs(gv - v64).max() <= TOL, np.abs(gv - v64).max()
+    assert np.allclose(gpi.sum(1), 1, atol=1e-5)
+    # the feature-tensor entry point agrees bit for bit with the position entry point
+    fpi, fv = eng.forward_features(feats)
+    assert (fpi == gpi).all() and (fv == gv).all()
+    # a position's output does not depend on its batch neighbours (the tree parity tests rely on it)
+    perm = rng.permutation(B)
+    ppi, pv = eng.forward(*pos_soa([positions[i] for i in perm]))
+    assert (ppi == gpi[perm]).all() and (pv == gv[perm]).all()
+    spi, sv = eng.forward(*pos_soa(positions[:1]))
+    assert (spi[0] == gpi[0]).all() and sv[0] == gv[0]
+    L.or_net_free(onet)
+    eng.close()
+
+
+def test_synthetic_init_matches_oracle_stream():
+    """agz_net_init_synthetic and the oracle draw the same tensors from the shared draw stream"""
+    N, tower = 9, 1
+    onet = L.or_net_new(N, tower)
+    L.or_net_init_synthetic(onet, 11)
+    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    eng.init_synthetic(11)
+    positions = random_positions(N, 1, 30, seed=2)[:8]
+    feats = np.stack([orc.feats(p).reshape(-1) for p in positions])
+    pi64, v64 = oracle_forward64(onet, feats, N * N + 1)
+    gpi, gv = eng.forward(*pos_soa(positions))
+    assert np.abs(gpi - pi64).max() <= 1e-5 and np.abs(gv - v64).max() <= 1e-5
+    L.or_net_free(onet)
+    eng.close()
+
+
+def test_weight_shape_errors():
+    eng = ag.Engine(board_size=9, games=1, tower_height=1, num_readouts=8, max_nodes_per_game=16)
+    with pytest.raises(ag.AgzError) as ei:
+        eng.set_weights(0, 0, np.zeros(10, np.float32))
+    assert ei.value.status == ag._lib.BAD_SHAPE
+    assert eng.param_count(0, 0) == 3 * 3 * 17 * 256
+    assert eng.param_count(ag._lib.L_POLICY_FC, 0) == 162 * 82
+    eng.close()

@@ -1,0 +1,127 @@
+"""Whole self-play games on the GPU against the oracle.
+
+(1) external-network mode: the HIP search kernels drive a CPU network (the oracle's); every
+    finished game must equal the oracle's own selfplay() move for move, pi bit for bit.
+(2) the engine's own HIP network: the oracle's tree search is run with agz_net_forward as its
+    network callable, so both searches see the same numbers; games must again be identical.
+    This also proves that features built from ancestor boards equal features built from the
+    reference's delta history, and that NN outputs do not depend on batch composition.
+(3) size-independent properties on a larger run (BASELINE configs[1] shape, shortened)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import alphago_jl_amd as ag
+import orc
+from gpu_common import GpuNetForOracle
+from test_hostsim_selfplay import OracleNet, bits_equal, oracle_game
+
+pytestmark = pytest.mark.gpu
+L = orc.lib()
+
+
+def run(eng, games, network=None, max_steps=100000):
+    eng.start(games)
+    steps = 0
+    while steps < max_steps:
+        if network is None:
+            eng.step(8)
+            steps += 8
+        else:
+            eng.step_external(network)
+            steps += 1
+        if eng.stats()["games_finished"] >= games:
+            break
+    return eng.records(), eng.stats()
+
+
+def check_against_oracle(recs, net_for_oracle, N, readouts, seed, **kw):
+    moves = evals = 0
+    for r in recs:
+        o = oracle_game(N, net_for_oracle, readouts, seed, int(r["game_id"]), kw.get("resign_threshold", -0.9),
+                        kw.get("resign_disable_fraction", 0.05))
+        assert r["num_moves"] == o["num_moves"], r["game_id"]
+        assert (r["moves"] == o["moves"][: r["num_moves"]]).all()
+        assert r["result"] == o["result"]
+        assert r["was_resign"] == (o["result_string"] in (b"B+R", b"W+R"))
+        assert bits_equal(r["qs"], o["qs"]) and bits_equal(r["pis"], o["pis"])
+        moves += o["num_moves"]
+        evals += o["evals"]
+    return moves, evals
+
+
+@pytest.mark.parametrize("N,tower,readouts,games,slots", [(5, 1, 16, 4, 4), (5, 1, 16, 9, 3), (9, 1, 24, 2, 2)])
+def test_external_network_games_match_oracle(N, tower, readouts, games, slots):
+    net = OracleNet(N, tower, seed=0)
+    eng = ag.Engine(board_size=N, tower_height=0, games=slots, num_readouts=readouts, seed=1,
+                    external_network=1, record_capacity_games=games + 8)
+    recs, st = run(eng, games, network=net.on_feats)
+    assert len(recs) == games and st["pool_exhausted"] == 0
+    moves, evals = check_against_oracle(recs, net, N, readouts, 1)
+    assert st["positions"] == moves and st["evals"] == evals
+    eng.close()
+    net.close()
+
+
+@pytest.mark.parametrize("N,tower,readouts,games,slots,kw", [
+    (5, 1, 16, 4, 4, {}),                                   # BASELINE.json configs[0]
+    (5, 2, 16, 12, 5, dict(resign_threshold=-0.05, resign_disable_fraction=0.5)),
+    (9, 2, 32, 3, 3, {}),
+])
+def test_internal_network_games_match_oracle(N, tower, readouts, games, slots, kw):
+    eng = ag.Engine(board_size=N, tower_height=tower, games=slots, num_readouts=readouts, seed=2,
+                    record_capacity_games=games + 8, **kw)
+    eng.init_synthetic(0)
+    recs, st = run(eng, games)
+    assert len(recs) == games and st["pool_exhausted"] == 0
+    fwd = ag.Engine(board_size=N, tower_height=tower, games=1, num_readouts=8, max_nodes_per_game=16)
+    fwd.init_synthetic(0)
+    moves, evals = check_against_oracle(recs, GpuNetForOracle(fwd), N, readouts, 2, **kw)
+    assert st["positions"] == moves and st["evals"] == evals
+    # replay_position on the device reproduces the features the oracle rebuilds by replaying
+    r = recs[0]
+    if r["num_moves"]:
+        feats = eng.record_features(r["index"], r["num_moves"])
+        pos = orc.make_pos(N)
+        for k in range(r["num_moves"]):
+            assert (feats[k].reshape(17, N * N) == orc.feats(pos)).all(), k
+            _, pos = orc.play(pos, int(r["moves"][k]))
+    fwd.close()
+    eng.close()
+
+
+def test_properties_at_scale():
+    """9x9 / tower 2 / 64 games / 32 readouts: invariants that need no oracle"""
+    N, A = 9, 82
+    eng = ag.Engine(board_size=N, tower_height=2, games=64, num_readouts=32, seed=9, record_capacity_games=80)
+    eng.init_synthetic(0)
+    recs, st = run(eng, 64)
+    assert len(recs) == 64 and st["pool_exhausted"] == 0
+    assert sorted(r["game_id"] for r in recs) == list(range(64))
+    for r in recs:
+        n = r["num_moves"]
+        assert 1 <= n <= 113
+        assert r["result"] in (-1, 0, 1)
+        pis = r["pis"]
+        ok = ~np.isnan(pis).any(axis=1)
+        assert np.allclose(pis[ok].sum(1), 1, atol=1e-4) and (pis[ok] >= 0).all()
+        assert (np.abs(r["qs"]) <= 1.0 + 1e-6).all()
+        # every recorded game replays legally on the oracle and ends where the record says
+        pos = orc.make_pos(N)
+        for k in range(n):
+            rcode, pos = orc.play(pos, int(r["moves"][k]))
+            assert rcode == orc.OK
+        if not r["was_resign"]:
+            assert pos.done or pos.n >= 113
+            assert r["final_score"] == L.or_score(C.byref(pos))
+            assert r["result"] == L.or_result(C.byref(pos))
+    # same seed => same games (determinism across runs and across slot counts)
+    eng2 = ag.Engine(board_size=N, tower_height=2, games=16, num_readouts=32, seed=9, record_capacity_games=80)
+    eng2.init_synthetic(0)
+    recs2, _ = run(eng2, 24)
+    for r2 in recs2:
+        r1 = recs[int(r2["game_id"])]
+        assert (r1["moves"] == r2["moves"]).all() and bits_equal(r1["pis"], r2["pis"])
+    eng.close()
+    eng2.close()
