@@ -7,5 +7,9 @@ Julia call surface over the C ABI of include/agz.h."""
 from . import _lib
 from ._lib import AgzError, IllegalMove, load
 from .engine import Engine
+from .api import (BLACK, EMPTY, WHITE, GameRecord, GoEnv, MCTSPlayer, NeuralNet, PlayerMove, Position,
+                  extract_data, from_flat, from_kgs, from_sgf, get_feats, selfplay, to_flat, to_kgs, to_sgf)
 
-__all__ = ["Engine", "AgzError", "IllegalMove", "load", "_lib"]
+__all__ = ["Engine", "AgzError", "IllegalMove", "load", "_lib", "GoEnv", "Position", "PlayerMove", "NeuralNet",
+           "MCTSPlayer", "selfplay", "extract_data", "GameRecord", "get_feats", "to_flat", "from_flat",
+           "from_kgs", "to_kgs", "from_sgf", "to_sgf", "BLACK", "WHITE", "EMPTY"]

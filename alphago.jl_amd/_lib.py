@@ -91,6 +91,7 @@ def load():
         "agz_engine_sync": (i32, [E]),
         "agz_net_set_weights": (i32, [E, i32, i32, f32p, i64]),
         "agz_net_param_count": (i64, [E, i32, i32]),
+        "agz_net_get_weights": (i32, [E, i32, i32, f32p, i64]),
         "agz_net_init_synthetic": (i32, [E, u64]),
         "agz_net_forward": (i32, [E, i8p, i8p, i32p, i8p, i32, f32p, f32p]),
         "agz_net_forward_features": (i32, [E, f32p, i32, f32p, f32p]),

@@ -1,0 +1,377 @@
+"""Host-side mirror of the reference's call surface for the hot path, over the C ABI.
+
+Same names, argument meaning and error behaviour as tejank10/AlphaGo.jl so that the parity tests
+read like the reference's own tests -- GoEnv, Position, play_move / pass_move / all_legal_moves /
+score / result, NeuralNet, MCTSPlayer (initialize_game, tree_search, pick_move, play_move,
+should_resign, is_done, set_result, extract_data), selfplay -- with Python conventions: 0-based
+(row, col) coordinates, `None` for a pass, snake_case instead of `!`.  No arithmetic happens here:
+every method marshals arrays and makes one call into libagz (HIP, gfx950)."""
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import IllegalMove
+from .engine import Engine
+
+BLACK, WHITE, EMPTY = 1, -1, 0
+_KGS = "ABCDEFGHJKLMNOPQRST"
+_SGF = "abcdefghijklmnopqrstuvwxyz"
+
+PlayerMove = namedtuple("PlayerMove", "color move")       # board.jl:17-20
+
+_rules = {}
+
+
+def _rules_engine(N):
+    """a 1-slot engine used only for the batched rule kernels (agz_go_*) with B = 1"""
+    if N not in _rules:
+        _rules[N] = Engine(board_size=N, tower_height=0, games=1, num_readouts=1, max_nodes_per_game=8)
+    return _rules[N]
+
+
+class GoEnv:
+    """GoEnv(N, planes=17), src/game/go/go.jl:1-26"""
+
+    def __init__(self, board_size=19, planes=17):
+        assert planes % 2 == 1
+        self.N = board_size
+        self.action_space = board_size * board_size + 1
+        self.planes = (planes - 1) // 2
+        self.max_action_space = 361          # go.jl:24 (hard-coded in the reference)
+
+
+def to_flat(c, env):                          # coords.jl:5-7
+    return env.N * env.N if c is None else c[0] + env.N * c[1]
+
+
+def from_flat(f, env):                        # coords.jl:10-12
+    return None if f == env.N * env.N else (f % env.N, f // env.N)
+
+
+def from_kgs(s, env):                         # coords.jl:26-34
+    if s == "pass":
+        return None
+    return env.N - int(s[1:]), _KGS.index(s[0].upper())
+
+
+def to_kgs(c, env):                           # coords.jl:37
+    return "pass" if c is None else f"{_KGS[c[1]]}{env.N - c[0]}"
+
+
+def from_sgf(s):                              # coords.jl:14-20
+    return None if not s else (_SGF.index(s[1]), _SGF.index(s[0]))
+
+
+def to_sgf(c):                                # coords.jl:23
+    return "" if c is None else _SGF[c[1]] + _SGF[c[0]]
+
+
+class Position:
+    """GoPosition, src/game/go/board.jl:271-306.  board[row, col] in {-1, 0, +1}."""
+
+    def __init__(self, env, board=None, n=0, komi=7.5, caps=(0, 0), ko=None, recent=(), board_deltas=None,
+                 to_play=BLACK):
+        self.env = env
+        N = env.N
+        self.board = np.zeros((N, N), np.int8) if board is None else np.array(board, np.int8).reshape(N, N)
+        self.n = n
+        self.komi = float(np.float32(komi))
+        self.caps = tuple(caps)
+        self.ko = ko
+        self.recent = list(recent)
+        self.board_deltas = np.zeros((0, N, N), np.int8) if board_deltas is None else np.array(board_deltas, np.int8)
+        self.to_play = to_play
+        self.done = False
+
+    # flat views in the ABI's point order p = row + N*col
+    def _flat(self):
+        return np.ascontiguousarray(self.board.T).reshape(1, -1)
+
+    def _ko0(self):
+        return -1 if self.ko is None else to_flat(self.ko, self.env)
+
+    def soa(self):
+        """(board [P], deltas [7, P], ndeltas, to_play) for agz_net_forward / agz_features"""
+        N = self.env.N
+        d = np.zeros((7, N * N), np.int8)
+        k = self.board_deltas.shape[0]
+        for i in range(k):
+            d[i] = np.ascontiguousarray(self.board_deltas[i].T).reshape(-1)
+        return self._flat()[0], d, k, self.to_play
+
+    def all_legal_moves(self):                # board.jl:393-424
+        return _rules_engine(self.env.N).go_legal(self._flat(), [self.to_play], [self._ko0()])[0]
+
+    def is_move_legal(self, c):               # board.jl:376-391
+        return bool(self.all_legal_moves()[to_flat(c, self.env)])
+
+    def score(self):                          # board.jl:511-533
+        return float(_rules_engine(self.env.N).go_score(self._flat(), [self.komi])[0])
+
+    def result(self):                         # board.jl:535-544
+        s = self.score()
+        return 1 if s > 0 else -1 if s < 0 else 0
+
+    def result_string(self):                  # board.jl:546-555
+        s = self.score()
+        return f"B+{s:.1f}" if s > 0 else f"W+{-s:.1f}" if s < 0 else "DRAW"
+
+    def _copy(self):
+        p = Position(self.env, self.board.copy(), self.n, self.komi, self.caps, self.ko, list(self.recent),
+                     self.board_deltas.copy(), self.to_play)
+        return p                              # like deepcopy(GoPosition): done resets (board.jl:308-315)
+
+    def pass_move(self, mutate=False):        # board.jl:426-440
+        return self.play_move(None, mutate=mutate)
+
+    def flip_playerturn(self, mutate=False):  # board.jl:442-447
+        p = self if mutate else self._copy()
+        p.ko = None
+        p.to_play = -p.to_play
+        return p
+
+    def play_move(self, c, mutate=False):     # board.jl:451-509
+        env, N = self.env, self.env.N
+        a = to_flat(c, env)
+        bo, ko_o, nc, st = _rules_engine(N).go_play(self._flat(), [self.to_play], [self._ko0()], [a])
+        if st[0] == _lib.ILLEGAL_MOVE:
+            raise IllegalMove(_lib.ILLEGAL_MOVE, f"illegal move {c}")
+        new_board = bo[0].reshape(N, N).T.copy()
+        color = self.to_play
+        # delta = +color at the played point and wherever an opponent stone vanished (board.jl:479-481)
+        delta = np.where(new_board != self.board, color, 0).astype(np.int8)
+        p = self if mutate else self._copy()
+        was_pass_before = bool(self.recent) and self.recent[-1].move is None
+        p.board = new_board
+        p.n = self.n + 1
+        cap = int(nc[0])
+        p.caps = (self.caps[0] + cap, self.caps[1]) if color == BLACK else (self.caps[0], self.caps[1] + cap)
+        p.ko = None if ko_o[0] < 0 else from_flat(int(ko_o[0]), env)
+        p.recent = list(self.recent) + [PlayerMove(color, c)]
+        keep = self.board_deltas[: env.planes - 2]
+        p.board_deltas = np.concatenate([delta[None], keep], axis=0)
+        p.to_play = -color
+        p.done = c is None and was_pass_before
+        return p
+
+
+class NeuralNet:
+    """NeuralNet(env; tower_height), src/neural_net.jl:13-33 -- inference only"""
+
+    def __init__(self, env, tower_height=19, seed=0):
+        self.env = env
+        self.tower_height = tower_height
+        self.engine = Engine(board_size=env.N, tower_height=tower_height, games=1, num_readouts=1,
+                             max_nodes_per_game=8)
+        self.engine.init_synthetic(seed)      # Flux-default-equivalent init (glorot uniform, BN identity)
+
+    def set_weights(self, layer, kind, data):
+        self.engine.set_weights(layer, kind, data)
+
+    def __call__(self, positions):            # neural_net.jl:57-73
+        single = isinstance(positions, Position)
+        plist = [positions] if single else list(positions)
+        if plist and not isinstance(plist[0], Position):
+            feats = np.stack([np.asarray(p.feats, np.float32).reshape(-1) for p in plist])
+            pi, v = self.engine.forward_features(feats)
+        else:
+            soa = [p.soa() for p in plist]
+            pi, v = self.engine.forward(np.stack([s[0] for s in soa]), np.stack([s[1] for s in soa]),
+                                        [s[2] for s in soa], [s[3] for s in soa])
+        return (pi[0], float(v[0])) if single else (pi.T.copy(), v)      # pi is A x B like the reference
+
+    def forward_features(self, feats):
+        return self.engine.forward_features(feats)
+
+
+def get_feats(pos):                           # features.jl:24-26 -> [17, N, N] indexed [plane, row, col]
+    N = pos.env.N
+    b, d, k, tp = pos.soa()
+    f = _rules_engine(N).features(b[None], d[None], [k], [tp])[0]
+    return f.reshape(17, N, N).transpose(0, 2, 1).copy()
+
+
+class LeafView:
+    """what a duck-typed network receives per leaf: the 17 planes and the colour to play"""
+
+    def __init__(self, feats, N):
+        self.feats = feats
+        self.to_play = int(feats[16 * N * N])
+
+
+class NodeView:
+    """read-only view of an MCTSNode (src/mcts.jl:41-82) living on the device"""
+
+    def __init__(self, player, node):
+        self._p, self.id = player, node
+
+    @property
+    def _info(self):
+        return self._p.engine.node_info(0, self.id)
+
+    N = property(lambda s: s._info.N)
+    W = property(lambda s: s._info.W)
+    Q = property(lambda s: s._info.Q)
+    is_expanded = property(lambda s: bool(s._info.is_expanded))
+    losses_applied = property(lambda s: s._info.losses_applied)
+    fmove = property(lambda s: s._info.fmove)
+    child_N = property(lambda s: s._p.engine.node_floats(0, s.id, _lib.F_CHILD_N))
+    child_W = property(lambda s: s._p.engine.node_floats(0, s.id, _lib.F_CHILD_W))
+    child_prior = property(lambda s: s._p.engine.node_floats(0, s.id, _lib.F_CHILD_PRIOR))
+    child_action_score = property(lambda s: s._p.engine.node_scores(0, s.id))
+
+    @property
+    def child_Q(self):
+        return self.child_W / (np.float32(1) + self.child_N)
+
+    @property
+    def children(self):
+        ch = self._p.engine.node_children(0, self.id)
+        return {int(a): NodeView(self._p, int(c)) for a, c in enumerate(ch) if c >= 0}
+
+    @property
+    def position(self):
+        info = self._info
+        N = self._p.env.N
+        board = self._p.engine.node_board(0, self.id).reshape(N, N).T
+        pos = Position(self._p.env, board, info.pos.n, info.pos.komi, (info.pos.caps_black, info.pos.caps_white),
+                       None if info.pos.ko < 0 else from_flat(info.pos.ko, self._p.env), to_play=info.pos.to_play)
+        pos.done = bool(info.done)
+        return pos
+
+
+class MCTSPlayer:
+    """MCTSPlayer(env, network; num_readouts, two_player_mode, resign_threshold), mcts_play.jl:3-24.
+    `network` is any callable positions -> (pi A x B, v B); a NeuralNet of this package is evaluated
+    on the device, anything else receives LeafView objects."""
+
+    def __init__(self, env, network, num_readouts=800, two_player_mode=False, resign_threshold=-0.9, seed=0,
+                 game_id=0):
+        self.env = env
+        self.network = network
+        self.num_readouts = num_readouts
+        self.two_player_mode = two_player_mode
+        self.tau_threshold = -1 if two_player_mode else (env.N * env.N // 12) // 2 * 2
+        self.resign_threshold = resign_threshold
+        internal = isinstance(network, NeuralNet)
+        self.engine = Engine(board_size=env.N, tower_height=network.tower_height if internal else 0, games=1,
+                             num_readouts=num_readouts, parallel_readouts=64, two_player_mode=int(two_player_mode),
+                             resign_threshold=resign_threshold, seed=seed, external_network=0 if internal else 1)
+        if internal:
+            network.engine.copy_weights_to(self.engine)
+        self._game_id = game_id
+        self.qs, self.searches_pi = [], []
+        self.result, self.result_string = 0, ""
+        self._start = None
+
+    def initialize_game(self, pos=None):      # mcts_play.jl:110-118
+        pos = Position(self.env) if pos is None else pos
+        last = -1 if not pos.recent else to_flat(pos.recent[-1].move, self.env)
+        self.engine.tree_init(0, pos._flat()[0], n=pos.n, to_play=pos.to_play, ko=pos._ko0(), caps=pos.caps,
+                              last_move=last, komi=pos.komi)
+        self.engine.set_draw(0, self._game_id, 0)
+        self.qs, self.searches_pi = [], []
+        self.result, self.result_string = 0, ""
+        self._start = pos
+        self._moves = []
+
+    @property
+    def root(self):
+        return NodeView(self, self.engine.tree_root(0))
+
+    def _net_on_feats(self, feats):
+        N = self.env.N
+        pi, v = self.network([LeafView(f, N) for f in feats])
+        pi = np.asarray(getattr(pi, "data", pi), np.float32)
+        v = np.asarray(getattr(v, "data", v), np.float32).reshape(-1)
+        return np.ascontiguousarray(pi.T), v       # the reference returns A x B
+
+    def tree_search(self, parallel_readouts=8):    # mcts_play.jl:73-98
+        internal = isinstance(self.network, NeuralNet)
+        return self.engine.tree_search(0, parallel_readouts, None if internal else self._net_on_feats)
+
+    def pick_move(self):                      # mcts_play.jl:52-71
+        st, a = self.engine.pick_move(0)
+        if st == _lib.ASSERT_SOFTPICK:
+            raise AssertionError("child_N[fcoord] != 0 (mcts_play.jl:67)")
+        return from_flat(a, self.env)
+
+    def play_move(self, c):                   # mcts_play.jl:26-50
+        root = self.root
+        info = root._info
+        if not self.two_player_mode:
+            cn = root.child_N
+            with np.errstate(invalid="ignore", divide="ignore"):
+                if info.pos.n <= self.tau_threshold:
+                    pr = cn.astype(np.float64) ** 0.98
+                    self.searches_pi.append((pr / pr.sum()).astype(np.float32))
+                else:
+                    self.searches_pi.append(cn / cn.sum())
+        self.qs.append(np.float32(info.Q))
+        if not self.engine.play_move(0, to_flat(c, self.env)):
+            print("Illegal move")
+            if not self.two_player_mode:
+                self.searches_pi.pop()
+            self.qs.pop()
+            return False
+        self._moves.append(c)
+        return True
+
+    def should_resign(self):                  # mcts_play.jl:124
+        return bool(self.engine.should_resign(0))
+
+    def is_done(self):                        # mcts_play.jl:120
+        return self.result != 0 or bool(self.engine.is_done(0, self.engine.tree_root(0)))
+
+    def set_result(self, winner, was_resign):  # mcts_play.jl:100-108
+        self.result = winner
+        self.result_string = ("B+R" if winner == BLACK else "W+R") if was_resign else self.root.position.result_string()
+
+    def extract_data(self):                   # mcts_play.jl:126-139
+        assert len(self.searches_pi) == self.root._info.pos.n, "GoPosition history is incomplete"
+        pos = Position(self.env, komi=self._start.komi)
+        positions = []
+        for c in self._moves:
+            positions.append(pos)
+            pos = pos.play_move(c)
+        return positions, [p.copy() for p in self.searches_pi], [self.result] * len(positions)
+
+
+GameRecord = namedtuple("GameRecord", "game_id moves searches_pi qs result result_string was_resign")
+
+
+def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, **cfg):
+    """selfplay(env, nn, num_ro) (src/selfplay.jl:1-45) for `games` concurrent games on the device.
+    Returns one GameRecord per game, ordered by game id."""
+    slots = min(games, 1024) if slots is None else slots
+    eng = Engine(board_size=env.N, tower_height=nn.tower_height, games=slots, num_readouts=num_ro, seed=seed,
+                 record_capacity_games=games + 8, **cfg)
+    nn.engine.copy_weights_to(eng)
+    eng.start(games)
+    while eng.records_count() < games:
+        eng.step(16)
+    out = []
+    for r in eng.records():
+        if r["was_resign"]:
+            rs = "B+R" if r["result"] == BLACK else "W+R"
+        else:
+            s = r["final_score"]
+            rs = f"B+{s:.1f}" if s > 0 else f"W+{-s:.1f}" if s < 0 else "DRAW"
+        out.append(GameRecord(r["game_id"], [from_flat(int(a), env) for a in r["moves"]], list(r["pis"]),
+                              r["qs"], r["result"], rs, bool(r["was_resign"])))
+    st = eng.stats()
+    eng.close()
+    if st["pool_exhausted"]:
+        raise _lib.AgzError(_lib.POOL_EXHAUSTED, "node pool exhausted; raise max_nodes_per_game")
+    return out
+
+
+def extract_data(env, record):
+    """extract_data for a GameRecord: (positions, pis, results) with positions rebuilt by replay"""
+    pos = Position(env)
+    positions = []
+    for c in record.moves:
+        positions.append(pos)
+        pos = pos.play_move(c)
+    return positions, [np.array(p) for p in record.searches_pi], [record.result] * len(positions)

@@ -111,6 +111,9 @@ int64_t agz_net_param_count(const agz_engine* e, int32_t layer, int32_t kind) {
   if (!e || !e->impl) return -1;
   return e->impl->net().param_count(layer, kind);
 }
+agz_status agz_net_get_weights(agz_engine* e, int32_t layer, int32_t kind, float* out, int64_t count) {
+  return guard(e, [&](agz::Engine& E) { E.net().get(layer, kind, out, count); });
+}
 agz_status agz_net_init_synthetic(agz_engine* e, uint64_t seed) {
   return guard(e, [&](agz::Engine& E) { E.net().init_synthetic(seed); });
 }

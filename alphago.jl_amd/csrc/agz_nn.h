@@ -34,6 +34,7 @@ class Net {
 
   int64_t param_count(int layer, int kind) const;
   void set(int layer, int kind, const float* data, int64_t count);
+  void get(int layer, int kind, float* out, int64_t count) const;
   void init_synthetic(uint64_t seed);
 
   // Reserve activation workspace for up to `bcap` positions.

@@ -401,6 +401,21 @@ void Net::set(int layer, int kind, const float* data, int64_t count) {
   dirty_ = true;
 }
 
+void Net::get(int layer, int kind, float* out, int64_t count) const {
+  AGZ_REQUIRE(out != nullptr, AGZ_BAD_ARGUMENT, "agz_net_get_weights: null output");
+  const int64_t want = param_count(layer, kind);
+  AGZ_REQUIRE(want >= 0, AGZ_BAD_ARGUMENT, "agz_net_get_weights: no parameter (layer %d, kind %d)", layer, kind);
+  AGZ_REQUIRE(want == count, AGZ_BAD_SHAPE, "agz_net_get_weights: layer %d kind %d holds %lld floats, asked %lld",
+              layer, kind, (long long)want, (long long)count);
+  if (const ConvHost* c = conv(layer)) {
+    if (kind == AGZ_K_BN_EPS) out[0] = c->eps;
+    else std::memcpy(out, conv_field(const_cast<ConvHost*>(c), kind)->data(), sizeof(float) * (size_t)count);
+  } else {
+    const DenseHost* d = dense(layer);
+    std::memcpy(out, (kind == AGZ_K_WEIGHT ? d->w : d->b).data(), sizeof(float) * (size_t)count);
+  }
+}
+
 // glorot_uniform over nfan (Flux utils): limit = sqrt(6/(fan_in+fan_out)); the element stream
 // is the AGZ_SITE_WEIGHTS site of the draw header, so any consumer of that header (the test
 // oracle included) generates the same tensors from the same seed.

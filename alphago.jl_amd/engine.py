@@ -72,6 +72,23 @@ class Engine:
         d = _f32(np.asarray(data).reshape(-1, order="A") if isinstance(data, np.ndarray) else data)
         self._ck(self.L.agz_net_set_weights(self.h, layer, kind, _p(d, C.c_float), d.size))
 
+    def get_weights(self, layer, kind):
+        n = self.param_count(layer, kind)
+        out = np.zeros(n, np.float32)
+        self._ck(self.L.agz_net_get_weights(self.h, layer, kind, _p(out, C.c_float), n))
+        return out
+
+    def layers(self):
+        """every (layer, kind) pair of this network, in a stable order"""
+        t = self.tower_height
+        out = [(l, k) for l in list(range(0, 1 + 2 * t)) + [_lib.L_VALUE_CONV, _lib.L_POLICY_CONV] for k in range(7)]
+        out += [(l, k) for l in (_lib.L_VALUE_FC1, _lib.L_VALUE_FC2, _lib.L_POLICY_FC) for k in (0, 1)]
+        return out
+
+    def copy_weights_to(self, other):
+        for l, k in self.layers():
+            other.set_weights(l, k, self.get_weights(l, k))
+
     def param_count(self, layer, kind):
         return self.L.agz_net_param_count(self.h, layer, kind)
 

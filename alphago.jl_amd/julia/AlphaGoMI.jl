@@ -1,0 +1,432 @@
+#=
+AlphaGoMI.jl -- thin `ccall` layer that puts libagz.so (MI355X / gfx950) behind the call surface of
+tejank10/AlphaGo.jl's self-play hot path, so that `train()` / `selfplay` / the MCTSPlayer tests can
+run against it unchanged (SURVEY.md 8b; ABI in include/agz.h).
+
+NOTE: there is no `julia` binary in the build image, so this file has been written against the
+Julia manual and the ABI header but never executed.  It contains no arithmetic of its own: every
+function is argument marshalling (1-based <-> 0-based, column-major arrays passed as-is) around one
+C call.  The Python mirror (alphago.jl_amd/api.py), which IS exercised by the test-suite, has the
+same structure call for call.
+
+Index conventions: the reference is 1-based -- flat move f in 1:N^2+1 with f == N^2+1 the pass,
+coords (row, col) with row 1 at the top (src/game/go/coords.jl:5-12).  The ABI is 0-based:
+a = f - 1, point p = (row-1) + N*(col-1).  Julia arrays are column-major, which is exactly the
+layout the ABI documents for boards (N x N Int8), conv weights [kw,kh,cin,cout], dense [out,in],
+features N x N x 17 x B and pi A x B -- so arrays cross without copies or permutes.
+=#
+module AlphaGoMI
+
+export GoEnv, Position, NeuralNet, MCTSPlayer, selfplay, extract_data, initialize_game!,
+       tree_search!, pick_move, play_move!, should_resign, is_done, set_result!, all_legal_moves,
+       score, result, IllegalMove, to_flat, from_flat
+
+const libagz = get(ENV, "AGZ_LIB", joinpath(@__DIR__, "..", "libagz.so"))
+
+const BLACK, WHITE, EMPTY = 1, -1, 0
+
+struct IllegalMove <: Exception end          # src/AlphaGo.jl:8
+
+# ---- status codes (include/agz.h)
+const AGZ_OK, AGZ_ILLEGAL_MOVE, AGZ_ASSERT_DONE_NODE, AGZ_HISTORY_INCOMPLETE, AGZ_BAD_SHAPE,
+      AGZ_ASSERT_SOFTPICK = 0, 1, 2, 3, 4, 5
+
+# agz_config: field order and types must match include/agz.h exactly (112 bytes)
+struct AgzConfig
+  board_size::Int32; tower_height::Int32; games::Int32; num_readouts::Int32
+  parallel_readouts::Int32; two_player_mode::Int32
+  komi::Float32; reserved0::Float32
+  c_puct::Float64; dirichlet_noise_weight::Float64; resign_threshold::Float64
+  resign_disable_fraction::Float64
+  seed::UInt64; game_id_base::UInt64; game_id_stride::UInt64
+  max_nodes_per_game::Int32; device::Int32; external_network::Int32; stagger_moves::Int32
+  record_capacity_games::Int32; reserved1::Int32
+end
+
+struct AgzPositionInfo
+  n::Int32; to_play::Int32; ko::Int32; caps_black::Int32; caps_white::Int32
+  last_move::Int32; prev_move::Int32; history_len::Int32; komi::Float32
+end
+
+struct AgzNodeInfo
+  N::Float32; W::Float32; Q::Float32
+  parent::Int32; fmove::Int32; is_expanded::Int32; losses_applied::Int32; done::Int32
+  pos::AgzPositionInfo
+end
+
+struct AgzGameHeader
+  game_id::UInt64; num_moves::Int32; result::Int32; was_resign::Int32; resign_disabled::Int32
+  final_score::Float32; reserved::Int32
+end
+
+mutable struct Engine
+  handle::Ptr{Cvoid}
+  cfg::AgzConfig
+end
+
+function check(e::Engine, st::Integer)
+  st == AGZ_OK && return
+  msg = unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), e.handle))
+  st == AGZ_ILLEGAL_MOVE && throw(IllegalMove())                       # board.jl:265,470
+  st in (AGZ_ASSERT_DONE_NODE, AGZ_HISTORY_INCOMPLETE, AGZ_BAD_SHAPE, AGZ_ASSERT_SOFTPICK) &&
+    throw(AssertionError(msg))                                          # mcts.jl:190,196 ...
+  error("libagz status $st: $msg")
+end
+
+function Engine(; board_size = 19, tower_height = 19, games = 1, num_readouts = 800,
+                parallel_readouts = 8, two_player_mode = false, komi = 7.5, c_puct = 0.96,
+                dirichlet_noise_weight = 0.25, resign_threshold = -0.9,
+                resign_disable_fraction = 0.05, seed = 0, game_id_base = 0, game_id_stride = 1,
+                max_nodes_per_game = 0, device = 0, external_network = false,
+                record_capacity_games = 0)
+  cfg = AgzConfig(board_size, tower_height, games, num_readouts, parallel_readouts,
+                  two_player_mode ? 1 : 0, komi, 0f0, c_puct, dirichlet_noise_weight,
+                  resign_threshold, resign_disable_fraction, seed, game_id_base, game_id_stride,
+                  max_nodes_per_game, device, external_network ? 1 : 0, 0, record_capacity_games, 0)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  st = ccall((:agz_engine_create, libagz), Int32, (Ref{AgzConfig}, Ref{Ptr{Cvoid}}), cfg, h)
+  st == AGZ_OK || error("agz_engine_create: " *
+    unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), C_NULL)))
+  e = Engine(h[], cfg)
+  finalizer(x -> ccall((:agz_engine_destroy, libagz), Cvoid, (Ptr{Cvoid},), x.handle), e)
+  e
+end
+
+# ------------------------------------------------------------------ GoEnv / Position
+# GoEnv(N, planes), src/game/go/go.jl:1-26
+struct GoEnv
+  N::Int
+  action_space::Int
+  planes::Int
+  max_action_space::Int
+  rules::Engine                 # a 1-slot engine used for the batched rule kernels with B = 1
+end
+GoEnv(board_size::Int = 19, planes::Int = 17) =
+  GoEnv(board_size, board_size^2 + 1, (planes - 1) ÷ 2, 361,
+        Engine(board_size = board_size, tower_height = 0, games = 1, num_readouts = 1,
+               max_nodes_per_game = 8))
+
+to_flat(c, env::GoEnv) = c === nothing ? env.N^2 + 1 : env.N * (c[2] - 1) + c[1]   # coords.jl:6-7
+from_flat(f, env::GoEnv) = f == env.N^2 + 1 ? nothing : (1 + (f - 1) % env.N, 1 + (f - 1) ÷ env.N)
+
+struct PlayerMove
+  color::Int
+  move::Union{Nothing, NTuple{2, Int}}
+end
+
+# GoPosition, src/game/go/board.jl:271-306 (the liberty tracker lives on the device side)
+mutable struct Position
+  env::GoEnv
+  board::Matrix{Int8}
+  n::Int
+  komi::Float32
+  caps::NTuple{2, Int}
+  ko::Union{Nothing, NTuple{2, Int}}
+  recent::Vector{PlayerMove}
+  board_deltas::Array{Int8, 3}
+  to_play::Int
+  done::Bool
+end
+Position(env::GoEnv; board = zeros(Int8, env.N, env.N), n = 0, komi = 7.5, caps = (0, 0),
+         ko = nothing, recent = PlayerMove[], board_deltas = zeros(Int8, env.N, env.N, 0),
+         to_play = BLACK) =
+  Position(env, board, n, komi, caps, ko, recent, board_deltas, to_play, false)
+
+ko0(pos::Position) = pos.ko === nothing ? Int32(-1) : Int32(to_flat(pos.ko, pos.env) - 1)
+
+# all_legal_moves(pos) -> Vector{Int8}(A), board.jl:393-424
+function all_legal_moves(pos::Position)
+  e = pos.env.rules
+  out = zeros(Int8, pos.env.action_space)
+  check(e, ccall((:agz_go_legal, libagz), Int32,
+                 (Ptr{Cvoid}, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Int32, Ptr{Int8}),
+                 e.handle, pos.board, Int8[pos.to_play], Int32[ko0(pos)], 1, out))
+  out
+end
+
+# score(pos), board.jl:511-533
+function score(pos::Position)
+  e = pos.env.rules
+  out = zeros(Float32, 1)
+  check(e, ccall((:agz_go_score, libagz), Int32, (Ptr{Cvoid}, Ptr{Int8}, Ptr{Float32}, Int32, Ptr{Float32}),
+                 e.handle, pos.board, Float32[pos.komi], 1, out))
+  out[1]
+end
+result(pos::Position) = (s = score(pos); s > 0 ? 1 : s < 0 ? -1 : 0)          # board.jl:535-544
+
+# play_move!(pos, c; mutate = false), board.jl:451-509 / pass_move! :426-440
+function play_move!(pos::Position, c; mutate = false)
+  env = pos.env; e = env.rules; N = env.N
+  a = to_flat(c, env) - 1
+  newboard = similar(pos.board); ko = zeros(Int32, 1); ncap = zeros(Int32, 1); st = zeros(Int32, 1)
+  check(e, ccall((:agz_go_play, libagz), Int32,
+                 (Ptr{Cvoid}, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Ptr{Int32}, Int32, Ptr{Int8}, Ptr{Int32},
+                  Ptr{Int32}, Ptr{Int32}),
+                 e.handle, pos.board, Int8[pos.to_play], Int32[ko0(pos)], Int32[a], 1, newboard, ko, ncap, st))
+  st[1] == AGZ_ILLEGAL_MOVE && throw(IllegalMove())
+  delta = newboard .- pos.board                       # +color at the move AND where stones vanished?
+  # board.jl:479-481: delta[c] = color, delta[captured] = color  (so that prev = new - delta)
+  delta = Int8.(ifelse.(delta .!= 0, Int8(pos.to_play), Int8(0)))
+  caps = pos.to_play == BLACK ? (pos.caps[1] + ncap[1], pos.caps[2]) : (pos.caps[1], pos.caps[2] + ncap[1])
+  keep = min(size(pos.board_deltas, 3), env.planes - 2)
+  deltas = cat(dims = 3, reshape(delta, N, N, 1), pos.board_deltas[:, :, 1:keep])
+  recent = vcat(pos.recent, PlayerMove(pos.to_play, c))
+  done = c === nothing && !isempty(pos.recent) && pos.recent[end].move === nothing
+  newko = ko[1] < 0 ? nothing : from_flat(ko[1] + 1, env)
+  np = Position(env, newboard, pos.n + 1, pos.komi, caps, newko, recent, deltas, -pos.to_play, done)
+  if mutate
+    for f in fieldnames(Position); setfield!(pos, f, getfield(np, f)); end
+    return pos
+  end
+  np
+end
+pass_move!(pos::Position; mutate = false) = play_move!(pos, nothing; mutate = mutate)
+
+# ------------------------------------------------------------------ NeuralNet
+# NeuralNet(env; tower_height), src/neural_net.jl:13-33.  Parameters are set layer by layer with
+# agz_net_set_weights in Flux layout (conv [kw,kh,cin,cout], dense [out,in]); `load_flux!` walks a
+# Flux Chain in `params` order (conv W,b ; BN beta,gamma ; ...), as save_model does (train.jl:14-35).
+struct NeuralNet
+  env::GoEnv
+  tower_height::Int
+  engine::Engine
+end
+function NeuralNet(env::GoEnv; tower_height::Int = 19, seed = 0)
+  e = Engine(board_size = env.N, tower_height = tower_height, games = 1, num_readouts = 1,
+             max_nodes_per_game = 8)
+  check(e, ccall((:agz_net_init_synthetic, libagz), Int32, (Ptr{Cvoid}, UInt64), e.handle, seed))
+  NeuralNet(env, tower_height, e)
+end
+
+set_weights!(nn::NeuralNet, layer::Integer, kind::Integer, data::AbstractArray{Float32}) =
+  check(nn.engine, ccall((:agz_net_set_weights, libagz), Int32,
+                         (Ptr{Cvoid}, Int32, Int32, Ptr{Float32}, Int64),
+                         nn.engine.handle, layer, kind, data, length(data)))
+
+# (nn)(positions::Vector{Position}) -> (pi A x B, v 1 x B), src/neural_net.jl:57-68
+function (nn::NeuralNet)(positions::Vector{Position})
+  env = nn.env; N = env.N; B = length(positions)
+  boards = cat(dims = 3, (p.board for p in positions)...)
+  deltas = zeros(Int8, N, N, 7, B)
+  nd = zeros(Int32, B)
+  for (b, p) in enumerate(positions)
+    k = size(p.board_deltas, 3); nd[b] = k
+    deltas[:, :, 1:k, b] .= p.board_deltas
+  end
+  tp = Int8[p.to_play for p in positions]
+  pi = zeros(Float32, env.action_space, B); v = zeros(Float32, 1, B)
+  check(nn.engine, ccall((:agz_net_forward, libagz), Int32,
+        (Ptr{Cvoid}, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Ptr{Int8}, Int32, Ptr{Float32}, Ptr{Float32}),
+        nn.engine.handle, boards, deltas, nd, tp, B, pi, v))
+  pi, v
+end
+(nn::NeuralNet)(pos::Position) = ((p, v) = nn([pos]); (p[:, 1], v[1]))        # neural_net.jl:70-73
+
+# ------------------------------------------------------------------ MCTSPlayer (single tree, slot 0)
+# MCTSPlayer(env, network; num_readouts, two_player_mode, resign_threshold), mcts_play.jl:3-24.
+# `network` is any callable positions -> (pi, v) (duck-typed field, mcts_play.jl:5): a NeuralNet of
+# this module is evaluated on the device without leaving it; anything else (DummyNet, a Flux model)
+# receives the leaves' feature tensor through the select / incorporate split.
+mutable struct MCTSPlayer
+  env::GoEnv
+  network
+  num_readouts::Int
+  two_player_mode::Bool
+  τ_threshold::Int
+  qs::Vector{Float32}
+  searches_π::Vector{Vector{Float32}}
+  result::Int
+  result_string::String
+  resign_threshold::Float64
+  engine::Engine
+end
+function MCTSPlayer(env::GoEnv, network; num_readouts = 800, two_player_mode = false,
+                    resign_threshold = -0.9, seed = 0)
+  τ = two_player_mode ? -1 : (env.N * env.N ÷ 12) ÷ 2 * 2
+  th = network isa NeuralNet ? network.tower_height : 0
+  e = Engine(board_size = env.N, tower_height = th, games = 1, num_readouts = num_readouts,
+             parallel_readouts = 64, two_player_mode = two_player_mode,
+             resign_threshold = resign_threshold, seed = seed, external_network = !(network isa NeuralNet))
+  MCTSPlayer(env, network, num_readouts, two_player_mode, τ, Float32[], Vector{Float32}[], 0, "",
+             resign_threshold, e)
+end
+
+function initialize_game!(p::MCTSPlayer, pos = nothing)                        # mcts_play.jl:110-118
+  pos === nothing && (pos = Position(p.env))
+  last = isempty(pos.recent) ? -1 : to_flat(pos.recent[end].move, p.env) - 1
+  info = AgzPositionInfo(pos.n, pos.to_play, ko0(pos), pos.caps[1], pos.caps[2], last, -1, 0, pos.komi)
+  check(p.engine, ccall((:agz_tree_init, libagz), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Int8}, Ref{AgzPositionInfo}, Ptr{Int8}),
+        p.engine.handle, 0, pos.board, info, C_NULL))
+  p.result = 0; p.qs = Float32[]; p.searches_π = Vector{Float32}[]
+  p
+end
+
+function root(p::MCTSPlayer)
+  r = Ref{Int32}(0)
+  check(p.engine, ccall((:agz_tree_root, libagz), Int32, (Ptr{Cvoid}, Int32, Ref{Int32}), p.engine.handle, 0, r))
+  r[]
+end
+
+function node_info(p::MCTSPlayer, node)
+  info = Ref{AgzNodeInfo}()
+  check(p.engine, ccall((:agz_tree_node_info, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{AgzNodeInfo}),
+                        p.engine.handle, 0, node, info))
+  info[]
+end
+N(p::MCTSPlayer) = node_info(p, root(p)).N
+Q(p::MCTSPlayer) = node_info(p, root(p)).Q
+
+function child_N(p::MCTSPlayer)
+  out = zeros(Float32, p.env.action_space)
+  check(p.engine, ccall((:agz_tree_node_floats, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float32}),
+                        p.engine.handle, 0, root(p), 0, out))
+  out
+end
+
+# tree_search!(player, parallel_readouts = 8), mcts_play.jl:73-98; returns the number of leaves
+function tree_search!(p::MCTSPlayer, parallel_readouts = 8)
+  n = Ref{Int32}(0)
+  if p.network isa NeuralNet
+    check(p.engine, ccall((:agz_tree_search, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}),
+                          p.engine.handle, 0, parallel_readouts, n))
+    return Int(n[])
+  end
+  check(p.engine, ccall((:agz_tree_search_select, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}),
+                        p.engine.handle, 0, parallel_readouts, n))
+  B = Int(n[]); B == 0 && return 0
+  feats = zeros(Float32, p.env.N, p.env.N, 17, B)
+  check(p.engine, ccall((:agz_tree_leaf_features, libagz), Int32, (Ptr{Cvoid}, Int32, Ptr{Float32}),
+                        p.engine.handle, 0, feats))
+  π, v = p.network(feats)                       # A x B and B values, Float32
+  check(p.engine, ccall((:agz_tree_search_incorporate, libagz), Int32,
+                        (Ptr{Cvoid}, Int32, Ptr{Float32}, Ptr{Float32}),
+                        p.engine.handle, 0, Float32.(π), Float32.(vec(v))))
+  B
+end
+
+function pick_move(p::MCTSPlayer)                                               # mcts_play.jl:52-71
+  a = Ref{Int32}(0)
+  check(p.engine, ccall((:agz_tree_pick_move, libagz), Int32, (Ptr{Cvoid}, Int32, Ref{Int32}), p.engine.handle, 0, a))
+  from_flat(a[] + 1, p.env)
+end
+
+function play_move!(p::MCTSPlayer, c)                                           # mcts_play.jl:26-50
+  info = node_info(p, root(p))
+  π = child_N(p)
+  if !p.two_player_mode
+    # children_as_pi(root, n <= tau) (mcts.jl:241-252): the device records the same vector in its
+    # game record; the host copy here serves `searches_π` for callers that read the field directly
+    squash = info.pos.n <= p.τ_threshold
+    pr = squash ? Float64.(π) .^ 0.98 : π
+    push!(p.searches_π, Float32.(pr ./ sum(pr)))
+  end
+  push!(p.qs, info.Q)
+  ok = Ref{Int32}(0)
+  check(p.engine, ccall((:agz_tree_play_move, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}),
+                        p.engine.handle, 0, to_flat(c, p.env) - 1, ok))
+  if ok[] == 0
+    println("Illegal move")
+    !p.two_player_mode && pop!(p.searches_π)
+    pop!(p.qs)
+    return false
+  end
+  true
+end
+
+function should_resign(p::MCTSPlayer)                                           # mcts_play.jl:124
+  r = Ref{Int32}(0)
+  check(p.engine, ccall((:agz_tree_should_resign, libagz), Int32, (Ptr{Cvoid}, Int32, Ref{Int32}), p.engine.handle, 0, r))
+  r[] != 0
+end
+
+function is_done(p::MCTSPlayer)                                                 # mcts_play.jl:120
+  p.result != 0 && return true
+  r = Ref{Int32}(0)
+  check(p.engine, ccall((:agz_tree_is_done, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}),
+                        p.engine.handle, 0, root(p), r))
+  r[] != 0
+end
+
+function set_result!(p::MCTSPlayer, winner, was_resign)                         # mcts_play.jl:100-108
+  p.result = winner
+  p.result_string = was_resign ? (winner == BLACK ? "B+R" : "W+R") : "see final position"
+end
+
+# ------------------------------------------------------------------ batched self-play
+# selfplay(env, nn, num_ro) -> one finished game (src/selfplay.jl:1-45); with `games = G` the same
+# loop runs for G concurrent games on the device and a vector of GameRecord comes back.
+struct GameRecord
+  game_id::UInt64
+  moves::Vector{Int}                    # 1-based flat moves, N^2+1 = pass
+  searches_π::Vector{Vector{Float32}}
+  qs::Vector{Float32}
+  result::Int
+  result_string::String
+end
+
+function selfplay(env::GoEnv, nn::NeuralNet, num_ro::Int = 800; games::Int = 1, slots::Int = min(games, 1024),
+                  seed = 0)
+  e = Engine(board_size = env.N, tower_height = nn.tower_height, games = slots, num_readouts = num_ro,
+             seed = seed, record_capacity_games = games + 8)
+  copy_weights!(e, nn.engine)
+  check(e, ccall((:agz_selfplay_start, libagz), Int32, (Ptr{Cvoid}, Int64), e.handle, games))
+  while ccall((:agz_records_count, libagz), Int64, (Ptr{Cvoid},), e.handle) < games
+    check(e, ccall((:agz_selfplay_step, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, 16))
+  end
+  recs = GameRecord[]
+  A = env.action_space
+  for k in 0:games-1
+    h = Ref{AgzGameHeader}()
+    check(e, ccall((:agz_records_header, libagz), Int32, (Ptr{Cvoid}, Int64, Ref{AgzGameHeader}), e.handle, k, h))
+    n = Int(h[].num_moves)
+    moves = zeros(Int16, max(n, 1)); pis = zeros(Float32, A, max(n, 1)); qs = zeros(Float32, max(n, 1))
+    check(e, ccall((:agz_records_game, libagz), Int32, (Ptr{Cvoid}, Int64, Ptr{Int16}, Ptr{Float32}, Ptr{Float32}),
+                   e.handle, k, moves, pis, qs))
+    rs = h[].was_resign != 0 ? (h[].result == BLACK ? "B+R" : "W+R") :
+         h[].final_score > 0 ? "B+$(round(h[].final_score, digits = 1))" :
+         h[].final_score < 0 ? "W+$(round(-h[].final_score, digits = 1))" : "DRAW"
+    push!(recs, GameRecord(h[].game_id, Int.(moves[1:n]) .+ 1, [pis[:, i] for i in 1:n], qs[1:n],
+                           Int(h[].result), rs))
+  end
+  sort!(recs, by = r -> r.game_id)
+  games == 1 ? recs[1] : recs
+end
+
+# extract_data(player) -> (positions, pis, results), mcts_play.jl:126-139: positions are rebuilt by
+# replaying the moves from the empty board, every result entry is the final game result.
+function extract_data(env::GoEnv, rec::GameRecord)
+  positions = Position[]
+  pos = Position(env)
+  for f in rec.moves
+    push!(positions, pos)
+    pos = play_move!(pos, from_flat(f, env))
+  end
+  positions, deepcopy(rec.searches_π), fill(rec.result, length(rec.moves))
+end
+
+# every (layer, kind) of a network with `t` residual blocks (ids as in include/agz.h)
+function layer_kinds(t::Integer)
+  lk = Tuple{Int32, Int32}[]
+  for l in vcat(collect(0:2t), [-1, -2]), k in 0:6
+    push!(lk, (l, k))
+  end
+  for l in (-3, -4, -5), k in 0:1
+    push!(lk, (l, k))
+  end
+  lk
+end
+
+function copy_weights!(dst::Engine, src::Engine)
+  for (l, k) in layer_kinds(src.cfg.tower_height)
+    n = ccall((:agz_net_param_count, libagz), Int64, (Ptr{Cvoid}, Int32, Int32), src.handle, l, k)
+    buf = zeros(Float32, n)
+    check(src, ccall((:agz_net_get_weights, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Float32}, Int64),
+                     src.handle, l, k, buf, n))
+    check(dst, ccall((:agz_net_set_weights, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Float32}, Int64),
+                     dst.handle, l, k, buf, n))
+  end
+  dst
+end
+
+end # module

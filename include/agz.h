@@ -101,6 +101,8 @@ agz_status agz_engine_sync(agz_engine* e);
 agz_status agz_net_set_weights(agz_engine* e, int32_t layer, int32_t kind, const float* data,
                                int64_t count);
 int64_t agz_net_param_count(const agz_engine* e, int32_t layer, int32_t kind);
+/* read a parameter back in the layout it was set in (save_model, train.jl:14-35) */
+agz_status agz_net_get_weights(agz_engine* e, int32_t layer, int32_t kind, float* out, int64_t count);
 /* Flux-default-equivalent init from the draw stream (glorot-uniform, zero bias, BN identity,
  * eps 1e-5) -- the synthetic weights of SURVEY.md 8d */
 agz_status agz_net_init_synthetic(agz_engine* e, uint64_t seed);

@@ -1,0 +1,136 @@
+"""The reference's own test scenarios written against the host mirror of its API
+(alphago.jl_amd/api.py): GoEnv / Position / MCTSPlayer / NeuralNet / selfplay / extract_data.
+Each test cites the reference test it transcribes."""
+import numpy as np
+import pytest
+
+import alphago_jl_amd as ag
+from alphago_jl_amd import BLACK, WHITE, GoEnv, MCTSPlayer, NeuralNet, PlayerMove, Position, from_kgs, to_flat
+from orc import load_board
+from test_oracle_go import ALMOST_DONE
+
+pytestmark = pytest.mark.gpu
+N = 9
+
+
+def board2d(text):
+    return load_board(text, N).reshape(N, N).T     # flat p = row + N*col  ->  [row, col]
+
+
+class DummyNet:  # test/test_mcts_player.jl:10-32
+    def __init__(self, env, fake_priors=None, fake_value=0.0):
+        self.p = np.ones(env.action_space) / env.action_space if fake_priors is None else np.asarray(fake_priors)
+        self.v = fake_value
+
+    def __call__(self, positions):
+        if positions is None or len(positions) == 0:
+            raise ValueError("No positions passed!")
+        B = len(positions)
+        return np.tile(self.p[:, None], (1, B)), np.full(B, self.v)
+
+
+def test_go_rules_through_api():  # test_go.jl:380-516
+    env = GoEnv(N)
+    EMPTY_ROW = "." * N + "\n"
+    start = Position(env, board=board2d(".X.....OO\nX........\n" + EMPTY_ROW * 7), komi=6.5, caps=(1, 2))
+    p1 = start.play_move(from_kgs("C9", env))
+    assert (p1.board == board2d(".XX....OO\nX........\n" + EMPTY_ROW * 7)).all()
+    assert p1.n == 1 and p1.to_play == WHITE and p1.caps == (1, 2)
+    kb = Position(env, board=board2d(".OX......\nOX.......\n" + EMPTY_ROW * 7), komi=6.5, caps=(1, 2))
+    k1 = kb.play_move(from_kgs("A9", env))
+    assert k1.ko == from_kgs("B9", env) and k1.caps == (2, 2)
+    with pytest.raises(ag.IllegalMove):
+        k1.play_move(from_kgs("B9", env))
+    k2 = k1.pass_move().pass_move().play_move(from_kgs("B9", env))
+    assert k2.caps == (2, 3) and k2.ko == from_kgs("A9", env) and k2.n == 4
+    root = Position(env)
+    assert not root.done and not root.play_move(None).done and root.play_move(None).play_move(None).done
+    assert root.result_string() == "W+7.5"
+    # features.jl / test_features.jl:39-79
+    pos = Position(env)
+    for c in ((0, 0), (0, 1), (0, 2), (0, 3), (1, 1)):
+        pos = pos.play_move(c)
+    f = ag.get_feats(pos)
+    assert f.shape == (17, N, N) and pos.to_play == WHITE
+    assert (f[0] == board2d("...X.....\n" + EMPTY_ROW * 8)).all()
+    assert (f[1] == board2d("X.X......\n.X.......\n" + EMPTY_ROW * 7)).all()
+    assert (f[10:16] == 0).all() and (f[16] == -1).all()
+
+
+def almost_done_player(env):  # test_mcts_player.jl:68-77
+    probs = np.ones(env.action_space) * 0.001
+    probs[2:5] = 0.2
+    probs[-1] = 0.2
+    player = MCTSPlayer(env, DummyNet(env, fake_priors=probs))
+    pos = Position(env, board=board2d(ALMOST_DONE), n=70, komi=2.5, caps=(1, 4),
+                   recent=[PlayerMove(BLACK, (0, 1)), PlayerMove(WHITE, (0, 8))], to_play=BLACK)
+    player.initialize_game(pos)
+    return player
+
+
+def test_dont_pass_if_losing():  # test_mcts_player.jl:139-165
+    env = GoEnv(N)
+    player = almost_done_player(env)
+    assert player.root.position.score() == -0.5
+    for _ in range(20):
+        player.tree_search()
+    flat = to_flat(from_kgs("D9", env), env)
+    root = player.root
+    assert int(np.argmax(root.child_N)) == flat
+    assert root.children[flat].Q > 0
+    assert root.N >= 20
+    assert root.child_Q[-1] < 0
+    assert player.engine.pending_vlosses(0) == 0
+
+
+def test_cold_start_and_extract_data():  # test_mcts_player.jl:227-240, 285-321
+    env = GoEnv(N)
+    player = MCTSPlayer(env, DummyNet(env, fake_value=0.17))
+    player.initialize_game()
+    assert player.root.N == 0 and not player.root.is_expanded
+    player.tree_search(4)
+    assert player.root.N == 1 and player.root.Q == pytest.approx(0.085)
+    player = MCTSPlayer(env, DummyNet(env))
+    player.initialize_game()
+    player.tree_search()
+    assert player.play_move(None)
+    player.tree_search()
+    assert player.play_move(None)
+    assert player.is_done()
+    player.set_result(player.root.position.result(), False)
+    positions, pis, results = player.extract_data()
+    assert len(positions) == len(pis) == len(results) == 2
+    assert results[0] == WHITE and player.result_string == "W+7.5"
+    player = MCTSPlayer(env, DummyNet(env))
+    player.initialize_game()
+    player.tree_search()
+    player.play_move((0, 0))
+    player.tree_search()
+    player.play_move(None)
+    player.tree_search()
+    assert player.root.position.result() == BLACK
+    player.set_result(WHITE, True)
+    assert player.extract_data()[2][0] == WHITE and player.result_string == "W+R"
+
+
+def test_neuralnet_and_selfplay_api():  # src/neural_net.jl:57-73, src/selfplay.jl, mcts_play.jl:126-139
+    env = GoEnv(5)
+    nn = NeuralNet(env, tower_height=1, seed=0)
+    pos = Position(env).play_move((2, 2))
+    pi, v = nn([pos, pos.play_move((1, 1))])
+    assert pi.shape == (26, 2) and np.allclose(pi.sum(0), 1, atol=1e-5) and abs(v).max() < 1
+    p1, v1 = nn(pos)
+    assert (p1 == pi[:, 0]).all() and v1 == v[0]
+    # an MCTSPlayer whose network is the HIP NeuralNet itself
+    player = MCTSPlayer(env, nn, num_readouts=16)
+    player.initialize_game()
+    for _ in range(4):
+        player.tree_search()
+    assert player.root.N >= 4 and player.engine.pending_vlosses(0) == 0
+    recs = ag.selfplay(env, nn, 16, games=3, seed=1)
+    assert [r.game_id for r in recs] == [0, 1, 2]
+    for r in recs:
+        positions, pis, results = ag.extract_data(env, r)
+        assert len(positions) == len(pis) == len(results) == len(r.moves) >= 1
+        assert all(z == r.result for z in results)
+        assert positions[0].n == 0 and positions[-1].n == len(r.moves) - 1
