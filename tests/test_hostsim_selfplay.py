@@ -62,6 +62,8 @@ def run_engine(N, net, readouts, seed, games, slots, max_steps=200000, **cfg):
 
 
 def bits_equal(a, b):
+    if a is None or b is None:      # a game that resigned before its first move records nothing
+        return (a is None or np.size(a) == 0) and (b is None or np.size(b) == 0)
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)
     nan_a, nan_b = np.isnan(a), np.isnan(b)
