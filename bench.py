@@ -121,6 +121,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # Setup, untimed and separate from the W warm-up steps: bring the synthetic state to the
+    # steady regime.  With --stagger every initial game gets a random opening prefix and a random
+    # fraction of its first readout budget (that shortened first move is never counted as a
+    # position), so after ceil(R/8) steps every game is mid-search at a uniformly random phase and
+    # K timed steps see K*8/R completed full-budget moves per game on average, for any K.
+    prelude = (R + 7) // 8 + 5 if args.stagger > 0 else 0
+    if prelude:
+        eng.step(prelude)
     eng.step(args.warmup)
     eng.sync()
     s0 = eng.stats()
@@ -162,6 +170,7 @@ def main():
                 "workload": f"GoEnv({N}), tower_height={tower}, {R} readouts, {args.games} concurrent games per GPU, "
                             f"8 leaves per game per step (batch <= {8 * args.games} positions)",
                 "games_per_gpu": args.games, "parallel_readouts": 8, "stagger_moves": args.stagger,
+                "setup_prelude_steps": prelude,
                 "weights": "synthetic glorot-uniform (seed 0), BN identity", "parallelism": f"games sharded x{world}",
             },
             "positions": d["positions"], "evals": d["evals"],

@@ -35,6 +35,7 @@ typedef struct {
   float *beta, *gamma, *mean, *var;  /* BN, [cout] */
   float eps;
   float* wp;                 /* packed [tap][cin][cout], flip applied */
+  float* wpn;                /* the same as 16-channel panels [cout/16][tap][cin][16] (cout % 16 == 0) */
   int dirty;
 } OConv;
 
@@ -57,6 +58,7 @@ static void conv_alloc(OConv* c, int k, int cin, int cout) {
   size_t nw = (size_t)k * k * cin * cout;
   c->w = (float*)calloc(nw, sizeof(float));
   c->wp = (float*)calloc(nw, sizeof(float));
+  c->wpn = (float*)calloc(nw, sizeof(float));
   c->b = (float*)calloc((size_t)cout, sizeof(float));
   c->beta = (float*)calloc((size_t)cout, sizeof(float));
   c->gamma = (float*)calloc((size_t)cout, sizeof(float));
@@ -67,7 +69,7 @@ static void conv_alloc(OConv* c, int k, int cin, int cout) {
   c->dirty = 1;
 }
 static void conv_free(OConv* c) {
-  free(c->w); free(c->wp); free(c->b); free(c->beta); free(c->gamma); free(c->mean); free(c->var);
+  free(c->w); free(c->wp); free(c->wpn); free(c->b); free(c->beta); free(c->gamma); free(c->mean); free(c->var);
 }
 static void dense_alloc(ODense* d, int in, int out) {
   d->in = in; d->out = out;
@@ -193,11 +195,24 @@ static void conv_pack(OConv* c) {
           c->wp[((size_t)tap * cin + ci) * cout + o] =
               c->w[a + (size_t)k * (b + (size_t)k * (ci + (size_t)cin * o))];
     }
+  if (cout % 16 == 0)
+    for (int nb = 0; nb < cout / 16; ++nb)
+      for (int tap = 0; tap < k * k; ++tap)
+        for (int ci = 0; ci < cin; ++ci)
+          memcpy(c->wpn + (((size_t)nb * k * k + tap) * cin + ci) * 16,
+                 c->wp + ((size_t)tap * cin + ci) * cout + nb * 16, 16 * sizeof(float));
   c->dirty = 0;
 }
 
 static int g_threads = 0;
 void or_set_num_threads(int n) { g_threads = n; }
+int or_get_num_procs(void) {
+#ifdef _OPENMP
+  return omp_get_num_procs();
+#else
+  return 1;
+#endif
+}
 
 #define T float
 #define SUF f32
