@@ -135,6 +135,9 @@ agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_
   return guard(e, [&](agz::Engine& E) { *ms_out = E.time_conv(B, iters); });
 }
 
+agz_status agz_net_set_winograd(agz_engine* e, int32_t on) {
+  return guard(e, [&](agz::Engine& E) { E.net().set_winograd(on != 0); });
+}
 agz_status agz_profile_conv_enable(agz_engine* e, int32_t on) {
   return guard(e, [&](agz::Engine& E) { E.net().profile_enable(on != 0); });
 }

@@ -45,6 +45,10 @@ class Net {
   // one tower conv launch on resident synthetic activations (for roofline timing)
   void launch_tower_conv_once(const int* d_count, int bcap);
 
+  // tower convolution algorithm: Winograd F(3x3,3x3) (default) or the direct implicit GEMM
+  void set_winograd(bool on) { winograd_ = on; }
+  bool winograd() const { return winograd_; }
+
   // HIP-event timing of every tower-conv launch inside forward() (bench.py roofline leg)
   void profile_enable(bool on);
   void profile_read(double* total_ms, double* total_flop, int64_t* launches);
@@ -74,6 +78,8 @@ class Net {
   // workspace
   int bcap_ = 0;
   DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
+  bool winograd_ = true;
+  DevBuf<float> d_uwino_, d_vimg_;        // transformed weights (stage images) / transformed activations
   // profiling
   bool prof_on_ = false;
   std::vector<hipEvent_t> prof_ev_;
@@ -82,6 +88,13 @@ class Net {
   int prof_n_ = 0, prof_fwd_ = 0;
   static constexpr int kProfMax = 4096;
 };
+
+// Winograd F(3x3,3x3) tower convolution (agz_wino.hip)
+void wino_pack_weights(const ConvHost& c, float* out);
+size_t wino_weight_floats();
+size_t wino_v_floats(int bcap, int T);
+void launch_wino_conv(const float* x, float* vimg, const float* uimg, const float* scale, const float* shift,
+                      const float* res, float* y, const int* d_count, int bcap, int N, int relu, hipStream_t s);
 
 // feature extraction entry points (features.jl:3-26) from the reference's own position format
 void launch_features_from_deltas(const int8_t* d_boards, const int8_t* d_deltas, const int32_t* d_ndeltas,

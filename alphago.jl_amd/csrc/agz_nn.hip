@@ -493,6 +493,12 @@ void Net::pack() {
     d_wtower_.ensure(w.size());
     AGZ_HIP(hipMemcpyAsync(d_wtower_.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
     AGZ_HIP(hipStreamSynchronize(stream_));
+    const size_t uper = wino_weight_floats();
+    std::vector<float> u(uper * 2 * tower_);
+    for (int l = 0; l < 2 * tower_; ++l) wino_pack_weights(tconv_[l], u.data() + uper * l);
+    d_uwino_.ensure(u.size());
+    AGZ_HIP(hipMemcpyAsync(d_uwino_.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
   }
   auto up = [&](DevBuf<float>& d, const std::vector<float>& h) {
     d.ensure(h.size());
@@ -527,6 +533,7 @@ void Net::reserve(int bcap) {
   d_t_.alloc(rows * kC);
   d_vh_.alloc(rows);
   d_ph_.alloc(rows * 2);
+  if (tower_ > 0) d_vimg_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
   bcap_ = bcap;
 }
 
@@ -545,13 +552,22 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
   for (int blk = 0; blk < tower_; ++blk) {
     const int l1 = 2 * blk, l2 = 2 * blk + 1;
     const bool p1 = prof_on_ && prof_n_ < kProfMax;
+    const size_t uper = wino_weight_floats();
     if (p1) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+    if (winograd_)
+      launch_wino_conv(a, d_vimg_.p, d_uwino_.p + uper * l1, d_scale_.p + (size_t)(l1 + 1) * kC,
+                       d_shift_.p + (size_t)(l1 + 1) * kC, nullptr, t, d_count, bcap, N_, 1, stream_);
+    else
     hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)a,
                        d_wtower_.p + per * l1, d_scale_.p + (size_t)(l1 + 1) * kC,
                        d_shift_.p + (size_t)(l1 + 1) * kC, (const float*)nullptr, t, d_count, N_, 1);
     if (p1) { (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_); prof_fwd_of_[prof_n_++] = prof_fwd_; }
     const bool p2 = prof_on_ && prof_n_ < kProfMax;
     if (p2) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+    if (winograd_)
+      launch_wino_conv(t, d_vimg_.p, d_uwino_.p + uper * l2, d_scale_.p + (size_t)(l2 + 1) * kC,
+                       d_shift_.p + (size_t)(l2 + 1) * kC, a, b, d_count, bcap, N_, 1, stream_);
+    else
     hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)t,
                        d_wtower_.p + per * l2, d_scale_.p + (size_t)(l2 + 1) * kC,
                        d_shift_.p + (size_t)(l2 + 1) * kC, (const float*)a, b, d_count, N_, 1);
@@ -606,6 +622,10 @@ void Net::launch_tower_conv_once(const int* d_count, int bcap) {
   reserve(bcap);
   AGZ_REQUIRE(tower_ > 0, AGZ_BAD_ARGUMENT, "no tower conv in a tower_height=0 network");
   const int grid = conv_grid(bcap, P_);
+  if (winograd_)
+    launch_wino_conv(d_a_.p, d_vimg_.p, d_uwino_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, d_t_.p, d_count, bcap,
+                     N_, 1, stream_);
+  else
   hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)d_a_.p,
                      d_wtower_.p, d_scale_.p + kC, d_shift_.p + kC, (const float*)nullptr, d_t_.p, d_count, N_, 1);
   AGZ_HIP(hipGetLastError());

@@ -132,6 +132,9 @@ class Engine:
         self._ck(self.L.agz_net_time_conv(self.h, B, iters, C.byref(ms)))
         return ms.value
 
+    def set_winograd(self, on=True):
+        self._ck(self.L.agz_net_set_winograd(self.h, 1 if on else 0))
+
     def profile_conv(self, on=True):
         self._ck(self.L.agz_profile_conv_enable(self.h, 1 if on else 0))
 

@@ -124,6 +124,10 @@ agz_status agz_net_time_forward(agz_engine* e, int32_t B, int32_t iters, float* 
 /* average duration (ms) of the dominant 3x3 256->256 conv launch over the same kind of run */
 agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_out);
 
+/* tower-convolution algorithm: 1 (default) = Winograd F(3x3,3x3) on the f32 MFMA, 0 = direct
+ * implicit GEMM on the f32 MFMA.  Both are f32 end to end; they differ by rounding only. */
+agz_status agz_net_set_winograd(agz_engine* e, int32_t on);
+
 /* HIP-event timing of every 3x3 256->256 tower-conv launch issued by subsequent steps /
  * forwards (up to 4096 launches), on the engine's own stream.  read() synchronises and returns
  * the summed launch time, the summed ALGORITHMIC flops (2 * rows * 9 * 256 * 256 with the rows

@@ -37,14 +37,16 @@ def test_features_exact(N):
     eng.close()
 
 
-@pytest.mark.parametrize("N,tower,B", [(5, 1, 7), (9, 2, 37), (9, 10, 16), (19, 3, 5)])
-def test_forward_matches_oracle(N, tower, B):
+@pytest.mark.parametrize("winograd", [1, 0])
+@pytest.mark.parametrize("N,tower,B", [(5, 1, 7), (9, 2, 37), (9, 10, 16), (19, 3, 5), (7, 2, 70)])
+def test_forward_matches_oracle(N, tower, B, winograd):
     A = N * N + 1
     rng = np.random.RandomState(N + tower)
     onet = L.or_net_new(N, tower)
     L.or_net_init_synthetic(onet, 3)
     randomize_bn(onet, list(range(0, 1 + 2 * tower)) + [orc.L_VALUE_CONV, orc.L_POLICY_CONV], rng)
     eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    eng.set_winograd(winograd)      # Winograd F(3x3,3x3) and the direct implicit GEMM must both hold 1e-4
     copy_weights_from_oracle(eng, onet, tower)
     positions = random_positions(N, 4, 80, seed=7)
     positions = [positions[i] for i in rng.choice(len(positions), B, replace=False)]

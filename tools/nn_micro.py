@@ -23,12 +23,13 @@ P = N * N
 eng = ag.Engine(board_size=N, tower_height=t, games=1, num_readouts=1, max_nodes_per_game=8)
 eng.init_synthetic(0)
 fe = 2.0 * P * (9 * 17 * 256 + t * 2 * 9 * 256 * 256) + 2.0 * P * 256 * 3 + 2.0 * (2 * P * (P + 1) + P * 256 + 256)
-for B in args.batches:
+for wino, B in [(w, b) for w in (1, 0) for b in args.batches]:
+    eng.set_winograd(wino)
     conv_ms = eng.time_conv(B, args.iters * 4)
     fwd_ms = eng.time_forward(B, args.iters)
     conv_tf = 2.0 * B * P * 9 * 256 * 256 / (conv_ms * 1e-3) / 1e12
     fwd_tf = B * fe / (fwd_ms * 1e-3) / 1e12
-    print(json.dumps({"board": N, "tower": t, "B": B, "conv_ms": conv_ms, "conv_TFLOPs": conv_tf,
-                      "conv_frac_of_peak": conv_tf / PEAK, "forward_ms": fwd_ms, "forward_TFLOPs": fwd_tf,
+    print(json.dumps({"board": N, "tower": t, "B": B, "algo": "winograd F(3x3,3x3)" if wino else "direct implicit GEMM", "conv_ms": conv_ms, "conv_TFLOPs": conv_tf,
+                      "conv_frac_of_peak(algorithmic flops / f32 MFMA peak)": conv_tf / PEAK, "forward_ms": fwd_ms, "forward_TFLOPs": fwd_tf,
                       "forward_frac_of_peak": fwd_tf / PEAK, "evals_per_s": B / (fwd_ms * 1e-3)}))
 eng.close()
