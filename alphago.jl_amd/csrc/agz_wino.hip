@@ -29,6 +29,7 @@
 #include "agz_nn.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace agz {
@@ -44,10 +45,12 @@ constexpr int A_STAGE = WXI * WT * WK;   // floats
 constexpr int B_STAGE = WXI * WC * WK;
 constexpr int STAGE = A_STAGE + B_STAGE;  // 19200 floats = 76.8 KB
 
-// physical position (in 2-float pairs) of logical k-pair g in the 8-float row `row`: rows r and
-// r+8 of a 16-row MFMA operand would hit the same banks under ds_read_b64; rotating the pairs by
-// two for rows with bit 3 set makes the 32 lanes of each read group cover all 64 banks once.
-__host__ __device__ __forceinline__ int wino_pair_pos(int row, int g) { return (g + 2 * ((row >> 3) & 1)) & 3; }
+// physical position (in 2-float pairs) of logical k-pair g in the 8-float row `row`.  A row is 8
+// dwords, so rows r, r+4, r+8, r+12 of a 16-row MFMA operand start on the same bank modulo 32 and
+// r, r+8 modulo 64; rotating the pairs by (row >> 2) gives every lane of a read group its own
+// 2-dword slot under BOTH LDS bankings -- ds_read_b64 (32-lane groups, 64 banks) and the
+// ds_read2st64_b64 pairs hipcc likes to fuse neighbouring planes into (16-lane groups, 32 banks).
+__host__ __device__ __forceinline__ int wino_pair_pos(int row, int g) { return (g + (row >> 2)) & 3; }
 
 // ------------------------------------------------------------------ input transform
 
@@ -117,12 +120,24 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
 
 // ------------------------------------------------------------------ GEMM + output transform
 
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// 16 bytes per lane straight from global memory into LDS (wave-uniform LDS base in M0 + lane*16).
+// Issued through inline asm on purpose: hipcc cannot prove that the DMA target (the OTHER stage
+// buffer) does not alias the ds_reads of the current stage and would put an s_waitcnt vmcnt(0) in
+// front of them, serialising load and compute (measured: 38 % MFMA utilisation).  An asm statement
+// is outside its vmcnt book-keeping, so the wait is placed by hand, once per stage, right before
+// the barrier that hands the buffer over.
+__device__ __forceinline__ void glds16(const float* g, unsigned lds_byte_addr) {
+  unsigned keep;
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);   // make the SGPR operand provable
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds_byte_addr)
+      : "memory");
 }
 
 // grid = tile blocks x (256 / WC); 512 threads = 8 waves: wm = wave & 3 -> 16 tiles, wn = wave >> 2 -> 16 couts
+template <int DBG>   // 0 = product; 1 = no DMA after stage 0 (compute ceiling); 2 = no MFMA (DMA ceiling): timing only
 __global__ __launch_bounds__(512, 2) void k_wino_gemm(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
@@ -140,9 +155,11 @@ __global__ __launch_bounds__(512, 2) void k_wino_gemm(
   const int tb = lid / NCB, cb = lid % NCB;
   if ((long)tb * WT >= Mt) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR)
   const int wm = wave & 3, wn = wave >> 2;
   const int l15 = lane & 15, hi = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0][0];
 
   const float* asrc = vimg + (long)tb * WNS * A_STAGE;
   const float* bsrc = uimg + (long)cb * WNS * B_STAGE;
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void k_wino_gemm(
     const float* b = bsrc + (long)st * B_STAGE;
     for (int c = wave; c < 75; c += 8) {
       const float* g = c < 50 ? a + c * 256 : b + (c - 50) * 256;
-      glds16(g + lane * 4, &lds[buf][c * 256]);
+      glds16(g + lane * 4, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
     }
   };
 
@@ -165,11 +182,13 @@ __global__ __launch_bounds__(512, 2) void k_wino_gemm(
   const int boff = A_STAGE + brow * WK + 2 * wino_pair_pos(brow, hi);
 
   issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int st = 0; st < WNS; ++st) {
     const int buf = st & 1;
-    if (st + 1 < WNS) issue(st + 1, buf ^ 1);
+    if (st + 1 < WNS && DBG != 1) issue(st + 1, buf ^ 1);
     const float* L = lds[buf];
+    if (DBG != 2)
 #pragma unroll
     for (int q5 = 0; q5 < 5; ++q5) {
       float2 a[5], b[5];
@@ -185,7 +204,8 @@ __global__ __launch_bounds__(512, 2) void k_wino_gemm(
       for (int j = 0; j < 5; ++j)
         acc[q5 * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc[q5 * 5 + j], 0, 0, 0);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage st+1 has landed
+    __syncthreads();                                    // ... and so has everybody else's
   }
 
   // epilogue: C/D map of the 16x16 MFMA -- col (cout) = lane & 15, row (tile) = 4*(lane>>4) + reg.
@@ -266,7 +286,9 @@ void launch_wino_conv(const float* x, float* vimg, const float* uimg, const floa
   const int T = (N + 2) / 3;
   const int blocks = (int)(((long)bcap * T * T + WT - 1) / WT);
   hipLaunchKernelGGL(k_wino_in, dim3(blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
-  hipLaunchKernelGGL(k_wino_gemm, dim3(blocks * (kC / WC)), dim3(512), 0, s, (const float*)vimg, uimg, scale, shift,
+  static const int dbg = getenv("AGZ_WINO_DEBUG") ? atoi(getenv("AGZ_WINO_DEBUG")) : 0;   // timing experiments only
+  auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : k_wino_gemm<0>;
+  hipLaunchKernelGGL(kern, dim3(blocks * (kC / WC)), dim3(512), 0, s, (const float*)vimg, uimg, scale, shift,
                      res, y, d_count, N, T, relu);
 }
 

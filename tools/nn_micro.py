@@ -16,6 +16,7 @@ ap.add_argument("--board", type=int, default=9)
 ap.add_argument("--tower", type=int, default=10)
 ap.add_argument("--batches", type=int, nargs="+", default=[1024, 4096, 8192])
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--algos", type=int, nargs="+", default=[1, 0], help="1 = winograd, 0 = direct")
 args = ap.parse_args()
 
 N, t = args.board, args.tower
@@ -23,7 +24,7 @@ P = N * N
 eng = ag.Engine(board_size=N, tower_height=t, games=1, num_readouts=1, max_nodes_per_game=8)
 eng.init_synthetic(0)
 fe = 2.0 * P * (9 * 17 * 256 + t * 2 * 9 * 256 * 256) + 2.0 * P * 256 * 3 + 2.0 * (2 * P * (P + 1) + P * 256 + 256)
-for wino, B in [(w, b) for w in (1, 0) for b in args.batches]:
+for wino, B in [(w, b) for w in args.algos for b in args.batches]:
     eng.set_winograd(wino)
     conv_ms = eng.time_conv(B, args.iters * 4)
     fwd_ms = eng.time_forward(B, args.iters)
