@@ -18,14 +18,18 @@
 //
 // Two kernels per layer:
 //   k_wino_in    X[M][256] -> V, the 25 transformed planes, written directly in the LDS image
-//                order of the GEMM stages (HBM-bound: reads 1 KB, writes 2.8 KB per board point)
+//                order of the GEMM stages (HBM-bound: reads 1 KB, writes 2.9 KB per board point)
 //   k_wino_gemm  25 GEMMs  M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout]  on
-//                v_mfma_f32_16x16x4_f32, all 25 accumulators of a (tile, cout) pair in ONE lane, so
+//                v_mfma_f32_32x32x2_f32.  A workgroup is 4 waves, ONE per SIMD, each owning a
+//                32-tile x 32-cout block of all 25 planes: 25 x 16 = 400 accumulator VGPRs of the
+//                512 a lone wave may use.  All 25 planes of a (tile, cout) pair sit in one lane, so
 //                the inverse transform A^T M A, the bias+BatchNorm affine, the residual add and the
 //                ReLU happen in registers in the epilogue: M is never written to memory.
-// Stage = 8 input channels x {64 tiles + 32 couts} x 25 planes = 76.8 KB, double-buffered in LDS
-// (153.6 KB of the CU's 160 KB) and filled by direct global->LDS DMA (global_load_lds_dwordx4),
-// which is why V and U are stored in HBM as ready-made, bank-swizzled stage images.
+// Stage = 4 input channels x {64 tiles + 64 couts} x 25 planes = 52 KB, triple-buffered in LDS and
+// filled by direct global->LDS DMA (global_load_lds_dwordx4), which is why V and U are stored in
+// HBM as ready-made, bank-swizzled stage images.  64x64 per workgroup gives 16 flop per DMA byte;
+// the first version (8 waves, 64x32, 16x16x4 MFMA) had 10.7 and was bound by the ~11 TB/s the
+// L2->LDS path delivered (measured with the MFMAs compiled out).
 #include "agz_nn.h"
 
 #include <cmath>
@@ -34,23 +38,28 @@
 
 namespace agz {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WT = 64;            // tiles per workgroup
-constexpr int WC = 32;            // output channels per workgroup
-constexpr int WK = 8;             // input channels per stage
-constexpr int WNS = kC / WK;      // stages
+constexpr int WC = 64;            // output channels per workgroup
+constexpr int WK = 4;             // input channels per stage
+constexpr int WNS = kC / WK;      // 64 stages
 constexpr int WXI = 25;
-constexpr int A_STAGE = WXI * WT * WK;   // floats
-constexpr int B_STAGE = WXI * WC * WK;
-constexpr int STAGE = A_STAGE + B_STAGE;  // 19200 floats = 76.8 KB
+constexpr int WPL = 13;           // LDS row planes: a row holds the 4 channels of TWO transform planes
+constexpr int A_STAGE = WPL * WT * 8;    // floats (26,624 B)
+constexpr int B_STAGE = WPL * WC * 8;
+constexpr int STAGE = A_STAGE + B_STAGE;  // 13,312 floats = 52 KB
 
-// physical position (in 2-float pairs) of logical k-pair g in the 8-float row `row`.  A row is 8
-// dwords, so rows r, r+4, r+8, r+12 of a 16-row MFMA operand start on the same bank modulo 32 and
-// r, r+8 modulo 64; rotating the pairs by (row >> 2) gives every lane of a read group its own
-// 2-dword slot under BOTH LDS bankings -- ds_read_b64 (32-lane groups, 64 banks) and the
-// ds_read2st64_b64 pairs hipcc likes to fuse neighbouring planes into (16-lane groups, 32 banks).
-__host__ __device__ __forceinline__ int wino_pair_pos(int row, int g) { return (g + (row >> 2)) & 3; }
+// A row of a stage image is 8 dwords = [plane 2q: 4 channels | plane 2q+1: 4 channels], i.e. four
+// 2-dword "pairs": logical pair = 2*(xi & 1) + h, h = which half of the 4 channels.  The 32 rows a
+// wave reads with one ds_read_b64 start on only 8 distinct banks (8 dwords * r mod 64), so the pairs
+// are rotated by f(row): rows r, r+8, r+16, r+24 (same bank mod 64, the 32-lane groups of
+// ds_read_b64) and rows r, r+4, r+8, r+12 (same bank mod 32, the 16-lane groups of the fused
+// ds_read2*_b64 forms hipcc may emit) all get distinct pair slots => conflict-free either way.
+__host__ __device__ __forceinline__ int wino_rot(int row) { return ((row >> 2) + (row >> 4)) & 3; }
+__host__ __device__ __forceinline__ int wino_pair_pos(int row, int xi, int h) {
+  return (2 * (xi & 1) + h + wino_rot(row)) & 3;
+}
 
 // ------------------------------------------------------------------ input transform
 
@@ -62,21 +71,21 @@ __device__ __forceinline__ void bt5(float x0, float x1, float x2, float x3, floa
   r[4] = 2.f * x1 - x2 - 2.f * x3 + x4;
 }
 
-// grid = tile blocks; 256 threads = 4 waves x (16 tiles x 4 channel pairs); loops over stages
-__global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
+// grid = tile blocks; 512 threads = 64 tiles x 8 channel pairs (= 4 consecutive stages x 2 halves):
+// the eight lanes of a tile read one 64-byte run of every patch point; loops over 16 stage groups.
+// Two channels per thread keep the kernel at ~120 VGPRs (4 waves/SIMD) -- it is HBM-bound.
+__global__ __launch_bounds__(512) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T) {
   const int P = N * N, TT = T * T;
   const long Mt = (long)(*d_count) * TT;
   const int tb = blockIdx.x;
   if ((long)tb * WT >= Mt) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane & 3;
-  const int tl = wave * 16 + (lane >> 2);           // tile within the block
+  const int hs = threadIdx.x & 7, h = hs & 1, sl = hs >> 1;
+  const int tl = threadIdx.x >> 3;                  // tile within the block
   const long tile = (long)tb * WT + tl;
   const bool live = tile < Mt;
   const int b = live ? (int)(tile / TT) : 0, t = live ? (int)(tile % TT) : 0;
   const int ti = t / T, tj = t % T;
-  // row offsets (in floats) of the 25 patch points, -1 where the point is off the board
   long off[25];
 #pragma unroll
   for (int u = 0; u < 5; ++u)
@@ -86,14 +95,16 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
       const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
       off[u * 5 + v] = ok ? ((long)b * P + pi + (long)N * pj) * kC : -1;
     }
-  const int gp = wino_pair_pos(tl, g);
-  float* dst0 = vimg + (long)tb * WNS * A_STAGE + (long)tl * WK + 2 * gp;
-  for (int st = 0; st < WNS; ++st) {
+  const int rot = wino_rot(tl);
+  float* img = vimg + (long)tb * WNS * A_STAGE + (long)tl * 8;
+  for (int sg = 0; sg < WNS / 4; ++sg) {
+    const int st = sg * 4 + sl;
     float2 d[25];
 #pragma unroll
     for (int q = 0; q < 25; ++q)
-      d[q] = off[q] >= 0 ? *reinterpret_cast<const float2*>(x + off[q] + st * WK + 2 * g) : make_float2(0.f, 0.f);
-    // V = B^T d B: first along u (rows) for every column v, then along v
+      d[q] = off[q] >= 0 ? *reinterpret_cast<const float2*>(x + off[q] + st * WK + 2 * h) : make_float2(0.f, 0.f);
+    float* dst = img + (long)st * A_STAGE;
+    // V = B^T d B, one channel component at a time
     float tx[25], ty[25];
 #pragma unroll
     for (int v = 0; v < 5; ++v) {
@@ -105,15 +116,17 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
 #pragma unroll
       for (int i = 0; i < 5; ++i) ty[i * 5 + v] = r[i];
     }
-    float* dst = dst0 + (long)st * A_STAGE;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       float rx[5], ry[5];
       bt5(tx[i * 5 + 0], tx[i * 5 + 1], tx[i * 5 + 2], tx[i * 5 + 3], tx[i * 5 + 4], rx);
       bt5(ty[i * 5 + 0], ty[i * 5 + 1], ty[i * 5 + 2], ty[i * 5 + 3], ty[i * 5 + 4], ry);
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
-        *reinterpret_cast<float2*>(dst + (long)(i * 5 + j) * WT * WK) = make_float2(rx[j], ry[j]);
+      for (int j = 0; j < 5; ++j) {
+        const int xi = i * 5 + j;
+        *reinterpret_cast<float2*>(dst + (long)(xi >> 1) * WT * 8 + 2 * ((2 * (xi & 1) + h + rot) & 3)) =
+            make_float2(rx[j], ry[j]);
+      }
     }
   }
 }
@@ -136,141 +149,205 @@ __device__ __forceinline__ void glds16(const float* g, unsigned lds_byte_addr) {
       : "memory");
 }
 
-// grid = tile blocks x (256 / WC); 512 threads = 8 waves: wm = wave & 3 -> 16 tiles, wn = wave >> 2 -> 16 couts
-template <int DBG>   // 0 = product; 1 = no DMA after stage 0 (compute ceiling); 2 = no MFMA (DMA ceiling): timing only
-__global__ __launch_bounds__(512, 2) void k_wino_gemm(
+// Inverse-transform coefficients A^T (3x5)
+__device__ __forceinline__ constexpr float wino_at(int o, int i) {
+  return o == 0 ? (i < 4 ? 1.f : 0.f)
+       : o == 1 ? (i == 1 ? 1.f : i == 2 ? -1.f : i == 3 ? 2.f : 0.f)
+                : (i == 1 ? 1.f : i == 2 ? 1.f : i == 3 ? 4.f : i == 4 ? 1.f : 0.f);
+}
+
+// grid = tile blocks x (256 / WC); 768 threads = 12 waves = 3 per SIMD.
+//   sp = wave & 3  -> which 32-tile x 32-cout quadrant of the 64 x 64 workgroup tile
+//   pg = wave >> 2 -> which third of the 25 transform planes (9 / 8 / 8) this wave accumulates
+// A wave therefore keeps 9 x 16 = 144 accumulator VGPRs and runs v_mfma_f32_32x32x2_f32 fed by two
+// ds_read_b64 per plane; the three plane groups of a quadrant land on the same SIMD, so every SIMD
+// owns 25 planes x 2 MFMAs x 64 cycles = 3200 MFMA-cycles per 4-channel stage.  The inverse
+// transform is linear in the planes: each wave reduces its own planes to a partial 3x3 output, the
+// partials of groups 1 and 2 cross to group 0 through the (by then idle) stage buffers in LDS.
+template <int DBG, int PG>
+__device__ __forceinline__ void wino_gemm_body(float (*lds)[STAGE], const float* __restrict__ asrc,
+                                               const float* __restrict__ bsrc, const float* __restrict__ scale,
+                                               const float* __restrict__ shift, const float* __restrict__ res,
+                                               float* __restrict__ y, long Mt, int N, int T, int relu, int tb,
+                                               int cb, int wave, int lane) {
+  constexpr int X0 = PG == 0 ? 0 : PG == 1 ? 9 : 17;     // first plane of this group
+  constexpr int NX = PG == 0 ? 9 : 8;
+  const int P = N * N, TT = T * T;
+  const int sp = wave & 3, wm = sp & 1, wn = sp >> 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0][0];
+
+  // a stage is 52 chunks of 1 KB (64 lanes x 16 B): chunks 0..25 from V, 26..51 from U
+  auto issue = [&](int st, int buf) {
+    const float* a = asrc + (long)st * A_STAGE;
+    const float* b = bsrc + (long)st * B_STAGE;
+    for (int c = wave; c < 52; c += 12) {
+      const float* g = c < 26 ? a + c * 256 : b + (c - 26) * 256;
+      glds16(g + lane * 4, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
+    }
+  };
+
+  f32x16 acc[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int arow = wm * 32 + l31, brow = wn * 32 + l31;
+  const int arot = wino_rot(arow), brot = wino_rot(brow);
+  const int abase = arow * 8, bbase = A_STAGE + brow * 8;
+
+  // Three stage buffers, two stages of DMA in flight: the L2->LDS path is latency-bound at one
+  // stage in flight (measured ~35 GB/s per CU), so the wait before a barrier is a COUNTED vmcnt
+  // that leaves the newest stage's requests (5 per wave for waves 0-3, 4 for the rest) outstanding.
+  const bool five = wave < 4;
+  issue(0, 0);
+  if (DBG != 1 && DBG != 3 && DBG != 4) issue(1, 1);
+  if (DBG == 1 || DBG == 3 || DBG == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (int st = 0; st < WNS; ++st) {
+    const int nbuf = buf == 0 ? 2 : buf - 1;            // (st + 2) % 3
+    const bool more = st + 2 < WNS && DBG != 1 && DBG != 3 && DBG != 4;
+    if (more) issue(st + 2, nbuf);
+    const float* L = lds[buf];
+    if (DBG != 2) {
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        constexpr int dummy = 0;
+        const int xi = X0 + k;
+        const int lp = 2 * (xi & 1) + hi;
+        float2 a = *reinterpret_cast<const float2*>(L + abase + (xi >> 1) * WT * 8 + 2 * ((lp + arot) & 3));
+        float2 b = *reinterpret_cast<const float2*>(L + bbase + (xi >> 1) * WC * 8 + 2 * ((lp + brot) & 3));
+        if (DBG == 4) { a = make_float2((float)st, 1.f); b = make_float2(2.f, (float)lane); }   // timing: no LDS reads
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[k], 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
+        (void)dummy;
+      }
+    }
+    // this wave's share of stage st+1 has landed (stage st+2 may still be in flight) ...
+    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (DBG != 3) __syncthreads();                      // ... and so has everybody else's
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+
+  // epilogue.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e&3) + 8*(e>>2) + 4*(lane>>5),
+  // so the planes of one (tile, cout) pair sit in the same lane and register index of the three waves.
+  float* xch = &lds[0][0];   // partial-output exchange: [pg-1][sp][e&3][9][64 lanes]
+  const int co = cb * WC + wn * 32 + l31;
+  const float sc = scale[co], sh = shift[co];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    float part[4][9];
+#pragma unroll
+    for (int el = 0; el < 4; ++el) {
+      const int e = qd * 4 + el;
+#pragma unroll
+      for (int oi = 0; oi < 3; ++oi)
+#pragma unroll
+        for (int oj = 0; oj < 3; ++oj) {
+          float v = 0.f;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) {
+            const int xi = X0 + k, i = xi / 5, j = xi % 5;
+            const float c = wino_at(oi, i) * wino_at(oj, j);
+            if (c != 0.f) v += c * acc[k][e];
+          }
+          part[el][oi * 3 + oj] = v;
+        }
+    }
+    if (PG != 0) {
+#pragma unroll
+      for (int el = 0; el < 4; ++el)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) xch[((((PG - 1) * 4 + sp) * 4 + el) * 9 + k) * 64 + lane] = part[el][k];
+    }
+    __syncthreads();
+    if (PG == 0) {
+#pragma unroll
+      for (int el = 0; el < 4; ++el) {
+        const int e = qd * 4 + el;
+        const long tile = (long)tb * WT + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (tile >= Mt) continue;
+        const int b = (int)(tile / TT), t = (int)(tile % TT);
+        const int ti = t / T, tj = t % T;
+#pragma unroll
+        for (int oi = 0; oi < 3; ++oi) {
+          const int pi = 3 * ti + oi;
+          if (pi >= N) continue;
+#pragma unroll
+          for (int oj = 0; oj < 3; ++oj) {
+            const int pj = 3 * tj + oj;
+            if (pj >= N) continue;
+            const int k = oi * 3 + oj;
+            const float yy = part[el][k] + xch[(((0 * 4 + sp) * 4 + el) * 9 + k) * 64 + lane] +
+                             xch[(((1 * 4 + sp) * 4 + el) * 9 + k) * 64 + lane];
+            const long m = (long)b * P + pi + (long)N * pj;
+            float v = yy * sc + sh;
+            if (res) v += res[m * kC + co];
+            if (relu) v = fmaxf(v, 0.f);
+            y[m * kC + co] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int DBG>   // timing experiments only: 0 = product; 1 = no DMA after stage 0; 2 = no MFMA; 3 = 1 + no barriers; 4 = 1 + no LDS reads
+__global__ __launch_bounds__(768, 3) void k_wino_gemm(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     const int* __restrict__ d_count, int N, int T, int relu) {
-  __shared__ __attribute__((aligned(16))) float lds[2][STAGE];
-  const int P = N * N, TT = T * T;
-  const long Mt = (long)(*d_count) * TT;
-
-  // XCD-aware bijective remap: the 8 cout blocks of one tile block are consecutive logical ids and
-  // therefore share an XCD, i.e. one L2 copy of that tile block's 1.6 MB slab of V.
+  __shared__ __attribute__((aligned(16))) float lds[3][STAGE];
+  const long Mt = (long)(*d_count) * T * T;
+  // XCD-aware bijective remap: the cout blocks of one tile block are consecutive logical ids and
+  // therefore share an XCD, i.e. one L2 copy of that tile block's slab of V.
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   constexpr int NCB = kC / WC;
   const int tb = lid / NCB, cb = lid % NCB;
   if ((long)tb * WT >= Mt) return;
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR)
-  const int wm = wave & 3, wn = wave >> 2;
-  const int l15 = lane & 15, hi = lane >> 4;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0][0];
-
   const float* asrc = vimg + (long)tb * WNS * A_STAGE;
   const float* bsrc = uimg + (long)cb * WNS * B_STAGE;
-  // a stage is 75 chunks of 1 KB (64 lanes x 16 B): chunks 0..49 from V, 50..74 from U
-  auto issue = [&](int st, int buf) {
-    const float* a = asrc + (long)st * A_STAGE;
-    const float* b = bsrc + (long)st * B_STAGE;
-    for (int c = wave; c < 75; c += 8) {
-      const float* g = c < 50 ? a + c * 256 : b + (c - 50) * 256;
-      glds16(g + lane * 4, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
-    }
-  };
-
-  f32x4 acc[WXI];
-#pragma unroll
-  for (int i = 0; i < WXI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int arow = wm * 16 + l15, brow = wn * 16 + l15;
-  const int aoff = arow * WK + 2 * wino_pair_pos(arow, hi);
-  const int boff = A_STAGE + brow * WK + 2 * wino_pair_pos(brow, hi);
-
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int st = 0; st < WNS; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < WNS && DBG != 1) issue(st + 1, buf ^ 1);
-    const float* L = lds[buf];
-    if (DBG != 2)
-#pragma unroll
-    for (int q5 = 0; q5 < 5; ++q5) {
-      float2 a[5], b[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        a[j] = *reinterpret_cast<const float2*>(L + aoff + (q5 * 5 + j) * WT * WK);
-        b[j] = *reinterpret_cast<const float2*>(L + boff + (q5 * 5 + j) * WC * WK);
-      }
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-        acc[q5 * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j].x, acc[q5 * 5 + j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-        acc[q5 * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc[q5 * 5 + j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage st+1 has landed
-    __syncthreads();                                    // ... and so has everybody else's
-  }
-
-  // epilogue: C/D map of the 16x16 MFMA -- col (cout) = lane & 15, row (tile) = 4*(lane>>4) + reg.
-  // All 25 planes of a (tile, cout) pair sit in this lane: Y = A^T M A in registers.
-  const int co = cb * WC + wn * 16 + l15;
-  const float sc = scale[co], sh = shift[co];
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg) {
-    const long tile = (long)tb * WT + wm * 16 + hi * 4 + rg;
-    if (tile >= Mt) continue;
-    const int b = (int)(tile / TT), t = (int)(tile % TT);
-    const int ti = t / T, tj = t % T;
-    float h[3][5];   // A^T M  (rows)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const float m0 = acc[0 * 5 + j][rg], m1 = acc[1 * 5 + j][rg], m2 = acc[2 * 5 + j][rg],
-                  m3 = acc[3 * 5 + j][rg], m4 = acc[4 * 5 + j][rg];
-      h[0][j] = m0 + m1 + m2 + m3;
-      h[1][j] = m1 - m2 + 2.f * m3;
-      h[2][j] = m1 + m2 + 4.f * m3 + m4;
-    }
-#pragma unroll
-    for (int oi = 0; oi < 3; ++oi) {
-      const float y0 = h[oi][0] + h[oi][1] + h[oi][2] + h[oi][3];
-      const float y1 = h[oi][1] - h[oi][2] + 2.f * h[oi][3];
-      const float y2 = h[oi][1] + h[oi][2] + 4.f * h[oi][3] + h[oi][4];
-      const float yy[3] = {y0, y1, y2};
-      const int pi = 3 * ti + oi;
-      if (pi >= N) continue;
-#pragma unroll
-      for (int oj = 0; oj < 3; ++oj) {
-        const int pj = 3 * tj + oj;
-        if (pj >= N) continue;
-        const long m = (long)b * P + pi + (long)N * pj;
-        float v = yy[oj] * sc + sh;
-        if (res) v += res[m * kC + co];
-        if (relu) v = fmaxf(v, 0.f);
-        y[m * kC + co] = v;
-      }
-    }
-  }
+  const int pg = wave >> 2;
+  if (pg == 0) wino_gemm_body<DBG, 0>(lds, asrc, bsrc, scale, shift, res, y, Mt, N, T, relu, tb, cb, wave, lane);
+  else if (pg == 1) wino_gemm_body<DBG, 1>(lds, asrc, bsrc, scale, shift, res, y, Mt, N, T, relu, tb, cb, wave, lane);
+  else wino_gemm_body<DBG, 2>(lds, asrc, bsrc, scale, shift, res, y, Mt, N, T, relu, tb, cb, wave, lane);
 }
 
 // ------------------------------------------------------------------ host side
 
-// Flux [kw,kh,cin,cout] column-major -> stage images U[cout block][stage][xi][cout 32][8 cin swizzled]
-// with U_xi = G k G^T computed in float64.  k is the CORRELATION kernel: NNlib's conv is a true
+// Flux [kw,kh,cin,cout] column-major -> stage images U[cout block][stage][plane][cout 64][8] with
+// U_xi = G k G^T computed in float64.  k is the CORRELATION kernel: NNlib's conv is a true
 // convolution, so tap (a', b') reading x[i + a' - 1, j + b' - 1] carries w[2 - a', 2 - b'].
 void wino_pack_weights(const ConvHost& c, float* out) {
   static const double G[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6, -1.0 / 6, 1.0 / 6},
                                  {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
   const int cin = c.cin, cout = c.cout;
+  std::memset(out, 0, sizeof(float) * wino_weight_floats());
   for (int o = 0; o < cout; ++o)
     for (int ci = 0; ci < cin; ++ci) {
       double k[3][3];
       for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) k[a][b] = c.w[(2 - a) + 3 * ((2 - b) + 3 * (ci + (size_t)cin * o))];
       const int cb = o / WC, ol = o % WC, st = ci / WK, cl = ci % WK;
-      const int pos = 2 * wino_pair_pos(ol, cl >> 1) + (cl & 1);
       for (int i = 0; i < 5; ++i)
         for (int j = 0; j < 5; ++j) {
           double u = 0.0;
           for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) u += G[i][a] * k[a][b] * G[j][b];
-          out[(((size_t)cb * WNS + st) * WXI + (i * 5 + j)) * WC * WK + (size_t)ol * WK + pos] = (float)u;
+          const int xi = i * 5 + j;
+          const int pos = 2 * wino_pair_pos(ol, xi, cl >> 1) + (cl & 1);
+          out[(((size_t)cb * WNS + st) * WPL + (xi >> 1)) * WC * 8 + (size_t)ol * 8 + pos] = (float)u;
         }
     }
 }
@@ -285,10 +362,10 @@ void launch_wino_conv(const float* x, float* vimg, const float* uimg, const floa
                       const float* res, float* y, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
   const int T = (N + 2) / 3;
   const int blocks = (int)(((long)bcap * T * T + WT - 1) / WT);
-  hipLaunchKernelGGL(k_wino_in, dim3(blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+  hipLaunchKernelGGL(k_wino_in, dim3(blocks), dim3(512), 0, s, x, vimg, d_count, N, T);
   static const int dbg = getenv("AGZ_WINO_DEBUG") ? atoi(getenv("AGZ_WINO_DEBUG")) : 0;   // timing experiments only
-  auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : k_wino_gemm<0>;
-  hipLaunchKernelGGL(kern, dim3(blocks * (kC / WC)), dim3(512), 0, s, (const float*)vimg, uimg, scale, shift,
+  auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : dbg == 3 ? k_wino_gemm<3> : dbg == 4 ? k_wino_gemm<4> : k_wino_gemm<0>;
+  hipLaunchKernelGGL(kern, dim3(blocks * (kC / WC)), dim3(768), 0, s, (const float*)vimg, uimg, scale, shift,
                      res, y, d_count, N, T, relu);
 }
 
