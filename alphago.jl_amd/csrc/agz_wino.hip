@@ -202,15 +202,15 @@ __device__ __forceinline__ void wino_gemm_body(float (*lds)[STAGE], const float*
   // that leaves the newest stage's requests (5 per wave for waves 0-3, 4 for the rest) outstanding.
   const bool five = wave < 4;
   issue(0, 0);
-  if (DBG != 1 && DBG != 3 && DBG != 4) issue(1, 1);
-  if (DBG == 1 || DBG == 3 || DBG == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (DBG != 1 && DBG != 3 && DBG != 4 && DBG != 5) issue(1, 1);
+  if (DBG == 1 || DBG == 3 || DBG == 4 || DBG == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __syncthreads();
   int buf = 0;
   for (int st = 0; st < WNS; ++st) {
     const int nbuf = buf == 0 ? 2 : buf - 1;            // (st + 2) % 3
-    const bool more = st + 2 < WNS && DBG != 1 && DBG != 3 && DBG != 4;
+    const bool more = st + 2 < WNS && DBG != 1 && DBG != 3 && DBG != 4 && DBG != 5;
     if (more) issue(st + 2, nbuf);
     const float* L = lds[buf];
     if (DBG != 2) {
@@ -221,7 +221,7 @@ __device__ __forceinline__ void wino_gemm_body(float (*lds)[STAGE], const float*
         const int lp = 2 * (xi & 1) + hi;
         float2 a = *reinterpret_cast<const float2*>(L + abase + (xi >> 1) * WT * 8 + 2 * ((lp + arot) & 3));
         float2 b = *reinterpret_cast<const float2*>(L + bbase + (xi >> 1) * WC * 8 + 2 * ((lp + brot) & 3));
-        if (DBG == 4) { a = make_float2((float)st, 1.f); b = make_float2(2.f, (float)lane); }   // timing: no LDS reads
+        if (DBG == 4 || DBG == 5) { a = make_float2((float)st, 1.f); b = make_float2(2.f, (float)lane); }   // timing: no LDS reads
         acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[k], 0, 0, 0);
         acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
         (void)dummy;
@@ -236,62 +236,90 @@ __device__ __forceinline__ void wino_gemm_body(float (*lds)[STAGE], const float*
   }
 
   // epilogue.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e&3) + 8*(e>>2) + 4*(lane>>5),
-  // so the planes of one (tile, cout) pair sit in the same lane and register index of the three waves.
-  float* xch = &lds[0][0];   // partial-output exchange: [pg-1][sp][e&3][9][64 lanes]
+  // so the planes of one (tile, cout) pair sit in the same lane and register index e of the three
+  // plane-group waves of a quadrant.  Each wave reduces ITS planes to a partial 3x3 output per e;
+  // the 16 register indices are owned 6 / 5 / 5 by the three groups, partials for foreign e's cross
+  // through LDS (the stage buffers are idle now), and every wave finalises its own e's -- affine,
+  // residual, ReLU, store -- so all 12 waves share the memory traffic.  Three rounds of 2+2+2 e's
+  // keep the exchange at 110 KB.
+  if (DBG == 5) {   // timing: K loop only -- keep the accumulators alive, skip the epilogue
+    float keep = 0.f;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) keep += acc[k][0] + acc[k][15];
+    if (keep == 123.456f) y[0] = keep;
+    return;
+  }
+  float* xch = &lds[0][0];   // [owner pg][source slot 0..1][sp][ei 0..1][9][64 lanes]
   const int co = cb * WC + wn * 32 + l31;
   const float sc = scale[co], sh = shift[co];
+  auto partial = [&](int e, float* out) {   // A^T M A restricted to this wave's planes
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    float part[4][9];
+    for (int oi = 0; oi < 3; ++oi)
 #pragma unroll
-    for (int el = 0; el < 4; ++el) {
-      const int e = qd * 4 + el;
+      for (int oj = 0; oj < 3; ++oj) {
+        float v = 0.f;
 #pragma unroll
-      for (int oi = 0; oi < 3; ++oi)
-#pragma unroll
-        for (int oj = 0; oj < 3; ++oj) {
-          float v = 0.f;
-#pragma unroll
-          for (int k = 0; k < NX; ++k) {
-            const int xi = X0 + k, i = xi / 5, j = xi % 5;
-            const float c = wino_at(oi, i) * wino_at(oj, j);
-            if (c != 0.f) v += c * acc[k][e];
-          }
-          part[el][oi * 3 + oj] = v;
+        for (int k = 0; k < NX; ++k) {
+          const int xi = X0 + k, i = xi / 5, j = xi % 5;
+          const float c = wino_at(oi, i) * wino_at(oj, j);
+          if (c != 0.f) v += c * acc[k][e];
         }
-    }
-    if (PG != 0) {
+        out[oi * 3 + oj] = v;
+      }
+  };
 #pragma unroll
-      for (int el = 0; el < 4; ++el)
+  for (int rd = 0; rd < 3; ++rd) {
+    // e's of this round: owner 0 -> {2rd, 2rd+1}; owner 1 -> {6+2rd, 7+2rd} (rd<2) or {10}; owner 2 -> {11+2rd, 12+2rd} or {15}
+    float own[2][9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) xch[((((PG - 1) * 4 + sp) * 4 + el) * 9 + k) * 64 + lane] = part[el][k];
+    for (int q = 0; q < 3; ++q) {
+      const int ne = (q == 0 || rd < 2) ? 2 : 1;
+#pragma unroll
+      for (int ei = 0; ei < 2; ++ei) {
+        if (ei >= ne) continue;
+        const int e = (q == 0 ? 0 : q == 1 ? 6 : 11) + 2 * rd + ei;
+        float part[9];
+        partial(e, part);
+        if (q == PG) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) own[ei][k] = part[k];
+        } else {
+          const int slot = PG < q ? PG : PG - 1;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) xch[((((q * 2 + slot) * 4 + sp) * 2 + ei) * 9 + k) * 64 + lane] = part[k];
+        }
+      }
     }
     __syncthreads();
-    if (PG == 0) {
+    {
+      const int ne = (PG == 0 || rd < 2) ? 2 : 1;
 #pragma unroll
-      for (int el = 0; el < 4; ++el) {
-        const int e = qd * 4 + el;
+      for (int ei = 0; ei < 2; ++ei) {
+        if (ei >= ne) continue;
+        const int e = (PG == 0 ? 0 : PG == 1 ? 6 : 11) + 2 * rd + ei;
         const long tile = (long)tb * WT + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
         if (tile >= Mt) continue;
         const int b = (int)(tile / TT), t = (int)(tile % TT);
         const int ti = t / T, tj = t % T;
+        long mrow[9];
+        float rv[9];
 #pragma unroll
-        for (int oi = 0; oi < 3; ++oi) {
-          const int pi = 3 * ti + oi;
-          if (pi >= N) continue;
+        for (int k = 0; k < 9; ++k) {   // nine residual loads issued back to back: one wait, not nine
+          const int pi = 3 * ti + k / 3, pj = 3 * tj + k % 3;
+          mrow[k] = (pi < N && pj < N) ? ((long)b * P + pi + (long)N * pj) * kC + co : -1;
+          rv[k] = (res && mrow[k] >= 0) ? res[mrow[k]] : 0.f;
+        }
 #pragma unroll
-          for (int oj = 0; oj < 3; ++oj) {
-            const int pj = 3 * tj + oj;
-            if (pj >= N) continue;
-            const int k = oi * 3 + oj;
-            const float yy = part[el][k] + xch[(((0 * 4 + sp) * 4 + el) * 9 + k) * 64 + lane] +
-                             xch[(((1 * 4 + sp) * 4 + el) * 9 + k) * 64 + lane];
-            const long m = (long)b * P + pi + (long)N * pj;
-            float v = yy * sc + sh;
-            if (res) v += res[m * kC + co];
-            if (relu) v = fmaxf(v, 0.f);
-            y[m * kC + co] = v;
-          }
+        for (int k = 0; k < 9; ++k) {
+          if (mrow[k] < 0) continue;
+          // fixed association (group0 + group1) + group2 whoever owns e: a position's result must
+          // not depend on which register index -- i.e. which batch row -- it happens to land on
+          const float x0 = xch[((((PG * 2 + 0) * 4 + sp) * 2 + ei) * 9 + k) * 64 + lane];
+          const float x1 = xch[((((PG * 2 + 1) * 4 + sp) * 2 + ei) * 9 + k) * 64 + lane];
+          const float yy = PG == 0 ? (own[ei][k] + x0) + x1 : PG == 1 ? (x0 + own[ei][k]) + x1 : (x0 + x1) + own[ei][k];
+          float v = yy * sc + sh + rv[k];
+          if (relu) v = fmaxf(v, 0.f);
+          y[mrow[k]] = v;
         }
       }
     }
@@ -306,13 +334,16 @@ __global__ __launch_bounds__(768, 3) void k_wino_gemm(
     const int* __restrict__ d_count, int N, int T, int relu) {
   __shared__ __attribute__((aligned(16))) float lds[3][STAGE];
   const long Mt = (long)(*d_count) * T * T;
-  // XCD-aware bijective remap: the cout blocks of one tile block are consecutive logical ids and
-  // therefore share an XCD, i.e. one L2 copy of that tile block's slab of V.
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  constexpr int NCB = kC / WC;
-  const int tb = lid / NCB, cb = lid % NCB;
+  // Workgroup -> (tile block, cout block) placement for the per-XCD L2 (4 MB, block b runs on XCD b % 8):
+  //   * even XCDs work on cout blocks {0,1}, odd XCDs on {2,3}: the transformed weights an XCD streams
+  //     over and over are 2 x 1.6 MB and stay L2-resident (with all four blocks per XCD the 6.5 MB
+  //     cyclic stream thrashed the L2 and U came from MALL/HBM: 7.5 GB per layer);
+  //   * the two cout blocks of a tile block are adjacent workgroups of one XCD and share the L2 copy
+  //     of that tile block's V slab, which is fetched from HBM by two XCDs (3.9 GB instead of 2).
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, j = bid >> 3;
+  const int cb = 2 * (xcd & 1) + (j & 1);
+  const int tb = (xcd >> 1) + 4 * (j >> 1);
   if ((long)tb * WT >= Mt) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR)
@@ -364,8 +395,9 @@ void launch_wino_conv(const float* x, float* vimg, const float* uimg, const floa
   const int blocks = (int)(((long)bcap * T * T + WT - 1) / WT);
   hipLaunchKernelGGL(k_wino_in, dim3(blocks), dim3(512), 0, s, x, vimg, d_count, N, T);
   static const int dbg = getenv("AGZ_WINO_DEBUG") ? atoi(getenv("AGZ_WINO_DEBUG")) : 0;   // timing experiments only
-  auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : dbg == 3 ? k_wino_gemm<3> : dbg == 4 ? k_wino_gemm<4> : k_wino_gemm<0>;
-  hipLaunchKernelGGL(kern, dim3(blocks * (kC / WC)), dim3(768), 0, s, (const float*)vimg, uimg, scale, shift,
+  auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : dbg == 3 ? k_wino_gemm<3> : dbg == 4 ? k_wino_gemm<4> : dbg == 5 ? k_wino_gemm<5> : k_wino_gemm<0>;
+  const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm
+  hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(768), 0, s, (const float*)vimg, uimg, scale, shift,
                      res, y, d_count, N, T, relu);
 }
 

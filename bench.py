@@ -200,7 +200,7 @@ def main():
             "end_to_end_mfma_frac": value * fpos / (world * PEAK_F32_MFMA_TFLOPS * 1e12),
             "roofline": {
                 "bound": "mfma",
-                "kernel": "3x3 256->256 tower conv = k_wino_in + k_wino_gemm (Winograd F(3x3,3x3), v_mfma_f32_16x16x4_f32)",
+                "kernel": "3x3 256->256 tower conv = k_wino_in + k_wino_gemm (Winograd F(3x3,3x3), v_mfma_f32_32x32x2_f32)",
                 "note": "achieved = ALGORITHMIC flops of the direct convolution (2*rows*9*256*256 per launch) / launch time; "
                         "Winograd executes 3.24x fewer multiplies, all in f32, so frac may exceed 1",
                 "achieved": conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
