@@ -117,6 +117,7 @@ def load():
         "agz_records_export_packed": (i32, [E, C.c_void_p, i64, i32]),
         "agz_records_clear": (i32, [E]),
         "agz_records_features": (i32, [E, i64, f32p]),
+        "agz_replay_features": (i32, [E, i16p, i64, i32p, i32p, i32, C.c_void_p, i32]),
         "agz_tree_init": (i32, [E, i32, i8p, P(PositionInfo), i8p]),
         "agz_tree_root": (i32, [E, i32, i32p]),
         "agz_tree_select_leaf": (i32, [E, i32, i32, i32p]),

@@ -185,6 +185,24 @@ class NeuralNet:
         return self.engine.forward_features(feats)
 
 
+def load_model(model_dir, env):
+    """load_model(str, env), src/play.jl:3-21: BSON parameter lists (and BatchNorm statistics when the
+    struct dumps are present) -> NeuralNet; the tower height is read off the base parameter list"""
+    from . import bson_weights as bw
+    ck = bw.read_checkpoint(model_dir)
+    nn = NeuralNet(env, tower_height=bw.tower_height_of(ck["base"]))
+    bw.apply_param_lists(nn.engine, ck["base"], ck["value"], ck["policy"], ck.get("base_stats"),
+                         ck.get("value_stats"), ck.get("policy_stats"))
+    return nn
+
+
+def save_model(nn, model_dir):
+    """save_model(nn), src/train.jl:14-35 (the reference hard-codes <repo>/models; here the directory
+    is an argument): writes weights/agz_{base,value,policy}.bson readable by Flux.loadparams!"""
+    from . import bson_weights as bw
+    bw.write_checkpoint(model_dir, bw.extract_param_lists(nn.engine))
+
+
 def get_feats(pos):                           # features.jl:24-26 -> [17, N, N] indexed [plane, row, col]
     N = pos.env.N
     b, d, k, tp = pos.soa()

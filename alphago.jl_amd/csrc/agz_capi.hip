@@ -201,6 +201,13 @@ agz_status agz_records_clear(agz_engine* e) { return guard(e, [&](agz::Engine& E
 agz_status agz_records_features(agz_engine* e, int64_t k, float* out) {
   return guard(e, [&](agz::Engine& E) { E.record_features(k, out); });
 }
+agz_status agz_replay_features(agz_engine* e, const int16_t* moves, int64_t nmoves, const int32_t* game_offset,
+                               const int32_t* ply, int32_t B, float* out, int32_t out_is_device) {
+  return guard(e, [&](agz::Engine& E) {
+    AGZ_REQUIRE(B == 0 || (game_offset && ply && out && (moves || nmoves == 0)), AGZ_BAD_ARGUMENT, "null pointer");
+    E.replay_batch_features(moves, nmoves, game_offset, ply, B, out, out_is_device != 0);
+  });
+}
 
 // ---- single-tree compat
 agz_status agz_tree_init(agz_engine* e, int32_t g, const int8_t* board, const agz_position_info* info,

@@ -40,6 +40,8 @@ class Engine {
   void records_export_packed(void* dst, int64_t capacity, bool is_device);
   void records_clear();
   void record_features(int64_t k, float* out);
+  void replay_batch_features(const int16_t* moves, int64_t nmoves, const int32_t* off, const int32_t* ply, int B,
+                             float* out, bool out_is_device);
 
   // network
   void net_forward_positions(const int8_t* boards, const int8_t* deltas, const int32_t* ndeltas,
@@ -96,6 +98,8 @@ class Engine {
   DevBuf<int8_t> s_boards_, s_deltas_, s_tp_, s_boards_out_, s_legal_;
   DevBuf<int32_t> s_i32a_, s_i32b_, s_i32c_, s_i32d_;
   DevBuf<float> s_f32a_, s_f32b_;
+  DevBuf<int16_t> s_i16a_;
+  DevBuf<int64_t> s_i64a_;
   DevBuf<double> s_f64_;
   DevBuf<int32_t> s_iout_;
   int external_batch_ = 0;

@@ -168,35 +168,49 @@ __global__ __launch_bounds__(kWave) void k_go_score(View V, const int8_t* boards
   go_score_one(w, V, S, boards + (long)b * V.P, komi[b], out + b);
 }
 
-// replay_position (board.jl:557-578) on the device: rebuild the 17 planes of every position of
-// a finished game from its move list.  One wave walks the game; out is [num_moves][17*P].
-__global__ __launch_bounds__(kWave) void k_replay_features(View V, const int16_t* moves, int nm, float komi,
-                                                            int8_t* hist /*[8][PP] scratch in HBM*/, float* out) {
+// replay_position (board.jl:557-578) on the device: rebuild the 17 planes of positions of a game
+// from its move list.  One wave walks one game: block b replays moves[off[b] .. off[b]+nm[b]) from
+// the empty board and writes the features of the position BEFORE move k for every k >= emit_from[b]
+// to out + out_off[b] + (k - emit_from[b]) * 17*P.  (record_features: one block, emit_from 0;
+// get_replay_batch, train.jl:4-12: one block per sampled (game, ply), nm = ply+1, emit_from = ply.)
+__global__ __launch_bounds__(kWave) void k_replay_features(View V, const int16_t* moves, const int32_t* off,
+                                                            const int32_t* nms, const int32_t* emit_from,
+                                                            const int64_t* out_off,
+                                                            int8_t* hist_all /*[blocks][8][PP] scratch in HBM*/,
+                                                            float* out_all) {
   AGZ_SCRATCH(S)
   HipWave w;
   const int P = V.P;
+  const int b = blockIdx.x;
+  moves += off[b];
+  const int nm = nms[b], from = emit_from[b];
+  int8_t* hist = hist_all + (long)b * 8 * V.PP;
+  float* out = out_all + out_off[b];
   // hist[0] = current board, hist[k] = k moves ago; avail = number of real older boards
   w.for_each(8 * V.PP, [&](int i) { hist[i] = 0; });
   w.sync();
-  int tp = 1, ko = -1, avail = 0;
+  int tp = 1, avail = 0;
   for (int k = 0; k < nm; ++k) {
-    w.for_each(P, [&](int p) {
-      float* dst = out + (long)k * 17 * P;
-      for (int s = 0; s < 8; ++s) {
-        const int t = s <= avail ? s : avail;
-        const int c = hist[t * V.PP + p];
-        dst[(2 * s) * P + p] = c == tp ? 1.f : 0.f;
-        dst[(2 * s + 1) * P + p] = c == -tp ? 1.f : 0.f;
-      }
-      dst[16 * P + p] = (float)tp;
-    });
-    w.sync();
+    if (k >= from) {
+      w.for_each(P, [&](int p) {
+        float* dst = out + (long)(k - from) * 17 * P;
+        for (int s = 0; s < 8; ++s) {
+          const int t = s <= avail ? s : avail;
+          const int c = hist[t * V.PP + p];
+          dst[(2 * s) * P + p] = c == tp ? 1.f : 0.f;
+          dst[(2 * s + 1) * P + p] = c == -tp ? 1.f : 0.f;
+        }
+        dst[16 * P + p] = (float)tp;
+      });
+      w.sync();
+    }
+    if (k + 1 == nm) break;      // the last listed move is never needed
     // play move k on hist[0]
     const int a = moves[k];
     w.for_each(P, [&](int p) { S.sb[p] = hist[p]; });
     w.sync();
     int ncap = 0, nko = -1;
-    if (a != P) {
+    if (a >= 0 && a < P) {
       label_components(w, V, S, true);
       group_liberties(w, V, S);
       apply_move_in_scratch(w, V, S, a, tp, &ncap, &nko);
@@ -207,11 +221,9 @@ __global__ __launch_bounds__(kWave) void k_replay_features(View V, const int16_t
     }
     w.for_each(P, [&](int p) { hist[p] = S.sb[p]; });
     w.sync();
-    ko = nko;
     tp = -tp;
     if (avail < 7) avail++;
   }
-  (void)ko; (void)komi;
 }
 
 __global__ void k_debug_draws(uint64_t seed, uint64_t game, uint32_t move, int n, double alpha, double* out) {
@@ -457,11 +469,58 @@ void Engine::record_features(int64_t k, float* out) {
   const size_t per = (size_t)17 * V_.P;
   s_f32a_.ensure(per * (size_t)h.num_moves);
   s_boards_.ensure((size_t)8 * V_.PP);
+  s_i32a_.ensure(3);
+  s_i64a_.ensure(1);
+  const int32_t args[3] = {0, h.num_moves, 0};
+  const int64_t zero = 0;
+  AGZ_HIP(hipMemcpyAsync(s_i32a_.p, args, sizeof(args), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i64a_.p, &zero, sizeof(zero), hipMemcpyHostToDevice, stream_));
   hipLaunchKernelGGL(k_replay_features, dim3(1), dim3(kWave), 0, stream_, V_,
-                     (const int16_t*)(V_.fin_moves + k * V_.max_game_length), h.num_moves, cfg_.komi, s_boards_.p,
-                     s_f32a_.p);
+                     (const int16_t*)(V_.fin_moves + k * V_.max_game_length), s_i32a_.p, s_i32a_.p + 1, s_i32a_.p + 2,
+                     s_i64a_.p, s_boards_.p, s_f32a_.p);
   AGZ_HIP(hipMemcpyAsync(out, s_f32a_.p, sizeof(float) * per * (size_t)h.num_moves, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+// get_replay_batch (train.jl:4-12), feature side: B sampled (game, ply) pairs -> [B][17*P].
+// moves: the games' action lists back to back; off[b] = where sample b's game starts; ply[b] = which
+// position of that game (0 = empty board).
+void Engine::replay_batch_features(const int16_t* moves, int64_t nmoves, const int32_t* off, const int32_t* ply,
+                                   int B, float* out, bool out_is_device) {
+  AGZ_REQUIRE(B >= 0 && nmoves >= 0, AGZ_BAD_ARGUMENT, "negative count");
+  if (B == 0) return;
+  std::vector<int32_t> h32((size_t)3 * B);
+  std::vector<int64_t> h64(B);
+  const size_t per = (size_t)17 * V_.P;
+  for (int b = 0; b < B; ++b) {
+    AGZ_REQUIRE(off[b] >= 0 && ply[b] >= 0 && (int64_t)off[b] + ply[b] <= nmoves, AGZ_BAD_ARGUMENT,
+                "sample points outside the move list");
+    AGZ_REQUIRE(ply[b] <= V_.max_game_length, AGZ_BAD_ARGUMENT, "ply beyond max_game_length");
+    h32[b] = off[b];
+    h32[B + b] = ply[b] + 1;
+    h32[2 * B + b] = ply[b];
+    h64[b] = (int64_t)b * (int64_t)per;
+  }
+  for (int64_t i = 0; i < nmoves; ++i)
+    AGZ_REQUIRE(moves[i] >= 0 && moves[i] <= V_.P, AGZ_BAD_ARGUMENT, "move outside 0..N*N");
+  s_i16a_.ensure((size_t)std::max<int64_t>(nmoves, 1));
+  s_i32a_.ensure((size_t)3 * B);
+  s_i64a_.ensure(B);
+  s_boards_.ensure((size_t)B * 8 * V_.PP);
+  float* dst = out;
+  if (!out_is_device) {
+    s_f32a_.ensure(per * (size_t)B);
+    dst = s_f32a_.p;
+  }
+  if (nmoves) AGZ_HIP(hipMemcpyAsync(s_i16a_.p, moves, sizeof(int16_t) * nmoves, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i32a_.p, h32.data(), sizeof(int32_t) * h32.size(), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i64a_.p, h64.data(), sizeof(int64_t) * h64.size(), hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_replay_features, dim3(B), dim3(kWave), 0, stream_, V_, (const int16_t*)s_i16a_.p, s_i32a_.p,
+                     s_i32a_.p + B, s_i32a_.p + 2 * B, s_i64a_.p, s_boards_.p, dst);
+  AGZ_HIP(hipGetLastError());
+  if (!out_is_device)
+    AGZ_HIP(hipMemcpyAsync(out, dst, sizeof(float) * per * (size_t)B, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));     // the staging vectors above are stack-owned
 }
 
 // ---- network entry points

@@ -20,16 +20,17 @@
 //   k_wino_in    X[M][256] -> V, the 25 transformed planes, written directly in the LDS image
 //                order of the GEMM stages (HBM-bound: reads 1 KB, writes 2.9 KB per board point)
 //   k_wino_gemm  25 GEMMs  M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout]  on
-//                v_mfma_f32_32x32x2_f32.  A workgroup is 4 waves, ONE per SIMD, each owning a
-//                32-tile x 32-cout block of all 25 planes: 25 x 16 = 400 accumulator VGPRs of the
-//                512 a lone wave may use.  All 25 planes of a (tile, cout) pair sit in one lane, so
-//                the inverse transform A^T M A, the bias+BatchNorm affine, the residual add and the
-//                ReLU happen in registers in the epilogue: M is never written to memory.
+//                v_mfma_f32_32x32x2_f32, 64 tiles x 64 couts x 25 planes per workgroup: 410 KB of
+//                accumulators, i.e. the CU's whole 512 KB register file is the tile.  12 waves =
+//                4 quadrants (32 x 32) x 3 plane groups (9/8/8 planes, 144 accumulator VGPRs each).
+//                The inverse transform A^T M A is linear in the planes: every wave reduces its own
+//                planes to a partial 3x3 output, the partials meet through the (by then idle) stage
+//                buffers in a FIXED order, and bias+BatchNorm affine, residual add and ReLU follow in
+//                registers: M is never written to memory.
 // Stage = 4 input channels x {64 tiles + 64 couts} x 25 planes = 52 KB, triple-buffered in LDS and
 // filled by direct global->LDS DMA (global_load_lds_dwordx4), which is why V and U are stored in
 // HBM as ready-made, bank-swizzled stage images.  64x64 per workgroup gives 16 flop per DMA byte;
-// the first version (8 waves, 64x32, 16x16x4 MFMA) had 10.7 and was bound by the ~11 TB/s the
-// L2->LDS path delivered (measured with the MFMAs compiled out).
+// the L2->LDS path (~11 TB/s measured with the MFMAs compiled out) and the MFMA pipe are co-critical.
 #include "agz_nn.h"
 
 #include <cmath>

@@ -230,6 +230,24 @@ class Engine:
         self._ck(self.L.agz_records_features(self.h, k, _p(out, C.c_float)))
         return out[:num_moves]
 
+    def replay_features(self, moves, game_offset, ply, out=None):
+        """features of sampled (game, ply) pairs by device replay (agz_replay_features).  `out` may be
+        a CUDA float32 torch tensor [B, 17*P] (filled in place, no host copy) or None -> numpy."""
+        moves = np.ascontiguousarray(moves, np.int16)
+        off = np.ascontiguousarray(game_offset, np.int32)
+        ply = np.ascontiguousarray(ply, np.int32)
+        B = len(off)
+        assert len(ply) == B
+        if out is None:
+            res = np.zeros((B, 17 * self.P), np.float32)
+            ptr, dev = res.ctypes.data_as(C.c_void_p), 0
+        else:
+            assert out.is_cuda and out.is_contiguous() and out.numel() == B * 17 * self.P and out.element_size() == 4
+            res, ptr, dev = out, C.c_void_p(out.data_ptr()), 1
+        self._ck(self.L.agz_replay_features(self.h, _p(moves, C.c_int16), moves.size, _p(off, C.c_int32),
+                                            _p(ply, C.c_int32), B, ptr, dev))
+        return res
+
     def records_packed(self):
         n = C.c_int64()
         self._ck(self.L.agz_records_packed_size(self.h, C.byref(n)))

@@ -37,6 +37,21 @@ def f_eval(N, t):
     return 2.0 * P * (9 * 17 * 256 + t * 2 * 9 * 256 * 256) + 2.0 * P * 256 * 3 + 2.0 * (2 * P * (P + 1) + P * 256 + 256)
 
 
+def pmc_traffic(rows_per_launch):
+    """HBM bytes per tower-conv launch, from the committed rocprofv3 --pmc passes.
+
+    Hardware counters cannot be read from inside this process; FETCH_SIZE and WRITE_SIZE were
+    collected in two separate `rocprofv3 --pmc` runs of tools/nn_micro.py (same kernels, full
+    8192-position batch) and summarised into profiles/pmc_traffic.json as bytes per board-point row.
+    Scaled here by the average rows per launch of THIS run.  None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        return d["bytes_per_row"] * rows_per_launch, f"profiles/pmc_traffic.json ({d['source']})"
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(N, tower, readouts, seconds):
     """oracle selfplay on the host cores; returns the cpu_baseline object"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -80,7 +95,7 @@ def cpu_baseline(N, tower, readouts, seconds):
     cores, t8 = best
     L.or_set_num_threads(cores)
     per_move = t8 * (readouts / 8.0 + 1.0)
-    moves = int(max(1, min(8, round(seconds / max(per_move, 1e-6)))))
+    moves = int(max(1, min(64, round(seconds / max(per_move, 1e-6)))))
     cb = orc.NET_FN(lambda ctx, pos, B, ppi, pv: L.or_net_callable(net, pos, B, ppi, pv))
     t0 = time.perf_counter()
     p = L.or_selfplay(N, cb, None, readouts, 1, 0, moves)
@@ -181,6 +196,9 @@ def main():
     if rank == 0:
         value = d["positions"] / elapsed
         fpos = R * f_eval(N, tower)
+        T = (N + 2) // 3
+        wino_ratio = 25.0 * T * T / (81.0 * N * N) * 9.0   # executed / algorithmic multiplies of F(3x3,3x3)
+        traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256))
         out = {
             "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)",
             "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,8 +224,12 @@ def main():
                 "achieved": conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": (conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
-                "traffic": None, "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
                 "flop_per_launch_avg": conv_flop / max(conv_n, 1),
+                # what the MFMA pipe actually executes: 25 multiplies per 3x3 output tile and (cin, cout)
+                "executed_flop_per_launch_avg": conv_flop * wino_ratio,
+                "executed_frac": (conv_flop * wino_ratio / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -200,6 +200,14 @@ agz_status agz_records_clear(agz_engine* e);
 /* replay_position(pos, result) board.jl:557-578 on the device: rebuild the feature tensors of
  * every position of record k: out float[num_moves][N*N*17] (WHC per position) */
 agz_status agz_records_features(agz_engine* e, int64_t k, float* out);
+/* get_replay_batch(pos_buffer, ...) train.jl:4-12, feature side, for records from ANY rank: the
+ * caller keeps games as action lists (moves int16[nmoves], games back to back); sample b is the
+ * position before move ply[b] of the game starting at moves[game_offset[b]] (ply 0 = empty board).
+ * One wave per sample replays the game on the device (board.jl:557-578) and writes
+ * out float[B][N*N*17] (same WHC order as agz_features); out may be a device pointer. */
+agz_status agz_replay_features(agz_engine* e, const int16_t* moves, int64_t nmoves,
+                               const int32_t* game_offset, const int32_t* ply, int32_t B, float* out,
+                               int32_t out_is_device);
 
 /* ---------------------------------------------------------------- single-tree compat ---- */
 /* The reference's MCTSPlayer / MCTSNode API on game slot g (tests drive these one call at a

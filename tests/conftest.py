@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# before any OpenMP runtime starts: the oracle's CPU network must not spin at barriers (see orc.lib)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 for p in (HERE, ROOT):

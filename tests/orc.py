@@ -65,6 +65,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
     path = os.path.join(ORACLE_DIR, "liboracle.so")
     if not os.path.exists(path) or os.path.exists("/root/reference"):
         # in the build container always rebuild (cheap, make is incremental)
@@ -155,8 +157,26 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    # The CPU network is OpenMP code; the GPU box reports 256 hardware threads but the container may
+    # own far fewer, and libgomp's spinning barriers then stall for minutes (seen: a 20 s suite taking
+    # > 15 min).  Tests are small: cap the team and never spin.
+    L.or_set_num_threads(default_threads())
     _lib = L
     return L
+
+
+def default_threads(cap=8):
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            avail = min(avail, int(float(q) / float(per) + 0.5))
+    except Exception:
+        pass
+    return max(1, min(cap, avail))
 
 
 # ---------------------------------------------------------------- fixtures helpers
