@@ -8,12 +8,12 @@ from . import _lib
 from ._lib import AgzError, IllegalMove, load
 from .engine import Engine
 from .api import (BLACK, EMPTY, WHITE, GameRecord, GoEnv, MCTSPlayer, NeuralNet, PlayerMove, Position,
-                  extract_data, from_flat, from_kgs, from_sgf, get_feats, load_model, save_model, selfplay, to_flat,
+                  evaluate, extract_data, from_flat, from_kgs, from_sgf, get_feats, load_model, save_model, selfplay, to_flat,
                   to_kgs, to_sgf)
 from . import bson_weights
 from .replay import ReplayBuffer
 
 __all__ = ["Engine", "AgzError", "IllegalMove", "load", "_lib", "GoEnv", "Position", "PlayerMove", "NeuralNet",
            "MCTSPlayer", "selfplay", "extract_data", "GameRecord", "get_feats", "to_flat", "from_flat",
-           "from_kgs", "to_kgs", "from_sgf", "to_sgf", "BLACK", "WHITE", "EMPTY", "load_model", "save_model",
+           "from_kgs", "to_kgs", "from_sgf", "to_sgf", "BLACK", "WHITE", "EMPTY", "load_model", "save_model", "evaluate",
            "bson_weights", "ReplayBuffer"]

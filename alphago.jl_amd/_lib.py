@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("resign_disable_fraction", C.c_double),
         ("seed", C.c_uint64), ("game_id_base", C.c_uint64), ("game_id_stride", C.c_uint64),
         ("max_nodes_per_game", C.c_int32), ("device", C.c_int32), ("external_network", C.c_int32),
-        ("stagger_moves", C.c_int32), ("record_capacity_games", C.c_int32), ("reserved1", C.c_int32),
+        ("stagger_moves", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
     ]
 
 
@@ -116,6 +116,8 @@ def load():
         "agz_records_packed_size": (i32, [E, P(i64)]),
         "agz_records_export_packed": (i32, [E, C.c_void_p, i64, i32]),
         "agz_records_clear": (i32, [E]),
+        "agz_arena_counts": (i32, [E, i32p]),
+        "agz_net_select": (i32, [E, i32]),
         "agz_records_features": (i32, [E, i64, f32p]),
         "agz_replay_features": (i32, [E, i16p, i64, i32p, i32p, i32, C.c_void_p, i32]),
         "agz_tree_init": (i32, [E, i32, i8p, P(PositionInfo), i8p]),

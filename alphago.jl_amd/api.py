@@ -385,6 +385,45 @@ def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, **cfg):
     return out
 
 
+EvalStats = namedtuple("EvalStats", "games_won num_games win_rate resigned moves records")
+
+
+def evaluate(env, black_net, white_net, num_games=400, ro=800, verbose=False, seed=0, slots=None,
+             return_stats=False, **cfg):
+    """evaluate(env, black_net, white_net; num_games, ro) (src/neural_net.jl:103-158): black_net plays
+    Black and white_net White in `num_games` games of two two_player_mode MCTSPlayers (arg-max moves,
+    no noise, resign at -0.9); True iff Black's win rate reaches 0.55.  All games run concurrently on
+    the device (arena_mode: one slot pair per game, both networks resident).  The tally follows the
+    reference literally: a game counts for Black when `result(black.root.position) == BLACK`, i.e.
+    by the Tromp-Taylor score of the final position, also after a resignation (:147)."""
+    if black_net.tower_height != white_net.tower_height:
+        raise ValueError("the arena keeps both networks in one engine: tower heights must match")
+    pairs = min(num_games, 512) if slots is None else slots
+    eng = Engine(board_size=env.N, tower_height=black_net.tower_height, games=2 * pairs, num_readouts=ro, seed=seed,
+                 arena_mode=1, record_capacity_games=num_games + 8, **cfg)
+    black_net.engine.copy_weights_to(eng)
+    eng.net_select(1)
+    white_net.engine.copy_weights_to(eng)
+    eng.net_select(0)
+    eng.start(num_games)
+    while eng.records_count() < num_games:
+        eng.step(16)
+    recs = eng.records()
+    st = eng.stats()
+    eng.close()
+    if st["pool_exhausted"]:
+        raise _lib.AgzError(_lib.POOL_EXHAUSTED, "node pool exhausted; raise max_nodes_per_game")
+    games_won = sum(1 for r in recs if r["final_score"] > 0)
+    rate = games_won / num_games
+    if verbose:
+        print(f"Won {games_won} / {num_games}. Win rate: {rate}. ", end="")
+    ok = rate >= 0.55
+    if return_stats:
+        return ok, EvalStats(games_won, num_games, rate, sum(int(r["was_resign"]) for r in recs),
+                             sum(int(r["num_moves"]) for r in recs), recs)
+    return ok
+
+
 def extract_data(env, record):
     """extract_data for a GameRecord: (positions, pis, results) with positions rebuilt by replay"""
     pos = Position(env)

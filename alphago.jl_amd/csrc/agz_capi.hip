@@ -66,6 +66,7 @@ void agz_config_default(agz_config* c) {
   c->num_readouts = 800;       // mcts_play.jl:17
   c->parallel_readouts = 8;    // mcts_play.jl:73
   c->two_player_mode = 0;
+  c->arena_mode = 0;
   c->komi = 7.5f;              // board.jl:297
   c->c_puct = 0.96;            // mcts.jl:11
   c->dirichlet_noise_weight = 0.25;   // mcts.jl:13
@@ -113,6 +114,15 @@ int64_t agz_net_param_count(const agz_engine* e, int32_t layer, int32_t kind) {
 }
 agz_status agz_net_get_weights(agz_engine* e, int32_t layer, int32_t kind, float* out, int64_t count) {
   return guard(e, [&](agz::Engine& E) { E.net().get(layer, kind, out, count); });
+}
+agz_status agz_net_select(agz_engine* e, int32_t which) {
+  return guard(e, [&](agz::Engine& E) { E.net_select(which); });
+}
+agz_status agz_arena_counts(agz_engine* e, int32_t* counts_out) {
+  return guard(e, [&](agz::Engine& E) {
+    AGZ_REQUIRE(counts_out, AGZ_BAD_ARGUMENT, "null pointer");
+    E.arena_counts(counts_out);
+  });
 }
 agz_status agz_net_init_synthetic(agz_engine* e, uint64_t seed) {
   return guard(e, [&](agz::Engine& E) { E.net().init_synthetic(seed); });

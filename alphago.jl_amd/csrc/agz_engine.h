@@ -20,7 +20,9 @@ class Engine {
 
   const agz_config& config() const { return cfg_; }
   const View& view() const { return V_; }
-  Net& net() { return *net_; }
+  Net& net() { return (net_sel_ && net2_) ? *net2_ : *net_; }   // the network agz_net_* calls address
+  void net_select(int which);
+  void arena_counts(int32_t* out) const;
   hipStream_t stream() const { return stream_; }
   void sync();
 
@@ -88,7 +90,9 @@ class Engine {
   agz_config cfg_;
   View V_{};
   hipStream_t stream_ = nullptr;
-  std::unique_ptr<Net> net_;
+  std::unique_ptr<Net> net_, net2_;   // net2_: White's network in arena mode
+  int net_sel_ = 0;
+  int external_batch2_ = 0;
   std::vector<void*> bufs_;
   size_t state_bytes_ = 0;
   int bcap_ = 0;

@@ -101,6 +101,36 @@ __global__ __launch_bounds__(kWave) void k_post(View V) {
 }
 
 // exclusive prefix sum of GameState::nleaves over the games -> leaf_base, total -> batch_count
+// arena: two batches, one per network.  Black players' leaves (even slots) get rows [0, n0), White
+// players' leaves rows [half, half + n1) with half = games*par/2: each network sees a contiguous
+// batch at a FIXED base, so no row offset has to come back to the host.
+__global__ __launch_bounds__(256) void k_scan_arena(View V) {
+  __shared__ int part[256];
+  const int t = threadIdx.x, npairs = V.games / 2;
+  const int chunk = (npairs + 255) / 256;
+  const int lo = t * chunk, hi = min(npairs, lo + chunk);
+  for (int c = 0; c < 2; ++c) {
+    int s = 0;
+    for (int p = lo; p < hi; ++p) s += V.gs[2 * p + c].nleaves;
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int v = t >= o ? part[t - o] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+    int base = part[t] - s + c * (npairs * V.par);
+    for (int p = lo; p < hi; ++p) {
+      V.gs[2 * p + c].leaf_base = base;
+      base += V.gs[2 * p + c].nleaves;
+    }
+    if (t == 255) V.batch_count[c] = part[255];
+    __syncthreads();
+  }
+  if (t == 255) atomicAdd(&V.counters[CT_STEPS], 1ull);
+}
+
 __global__ __launch_bounds__(256) void k_scan(View V) {
   __shared__ int part[256];
   const int t = threadIdx.x, G = V.games;
@@ -261,6 +291,8 @@ static void validate(const agz_config& c) {
   AGZ_REQUIRE(c.num_readouts >= 1, AGZ_BAD_ARGUMENT, "num_readouts must be >= 1");
   AGZ_REQUIRE(c.parallel_readouts >= 1 && c.parallel_readouts <= kMaxPar, AGZ_BAD_ARGUMENT,
               "parallel_readouts %d not in 1..%d", c.parallel_readouts, kMaxPar);
+  AGZ_REQUIRE(!c.arena_mode || (c.games % 2 == 0 && c.stagger_moves == 0), AGZ_BAD_ARGUMENT,
+              "arena_mode needs an even number of slots and no stagger");
 }
 
 Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
@@ -296,6 +328,7 @@ Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
   V_.v = d_v_.p;
   s_iout_.alloc(4);
   net_.reset(new Net(V_.N, cfg.tower_height, stream_));
+  if (cfg.arena_mode) net2_.reset(new Net(V_.N, cfg.tower_height, stream_));
   // every slot idle-retired until start()
   std::vector<GameState> gs(V_.games);
   std::memset(gs.data(), 0, sizeof(GameState) * gs.size());
@@ -308,14 +341,22 @@ Engine::~Engine() {
   (void)hipStreamSynchronize(stream_);
   for (void* p : bufs_) (void)hipFree(p);
   net_.reset();
+  net2_.reset();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 void Engine::sync() { AGZ_HIP(hipStreamSynchronize(stream_)); }
 
+void Engine::net_select(int which) {
+  AGZ_REQUIRE(which == 0 || (which == 1 && net2_), AGZ_BAD_ARGUMENT,
+              "network %d does not exist (network 1 needs arena_mode)", which);
+  net_sel_ = which;
+}
+
 void Engine::start(int64_t total_games) {
   V_.total_games = total_games;
   AGZ_HIP(hipMemsetAsync(V_.counters, 0, sizeof(unsigned long long) * CT_COUNT, stream_));
+  AGZ_HIP(hipMemsetAsync(V_.ar_hdr, 0, sizeof(int32_t) * 4 * (V_.games / 2 + 1), stream_));
   std::vector<GameState> gs(V_.games);
   std::memset(gs.data(), 0, sizeof(GameState) * gs.size());
   for (auto& g : gs) g.phase = G_IDLE;
@@ -328,9 +369,16 @@ void Engine::step(int nsteps) {
               "engine was created with external_network=1: use select/incorporate");
   for (int s = 0; s < nsteps; ++s) {
     hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream_, V_);
+    hipLaunchKernelGGL(cfg_.arena_mode ? k_scan_arena : k_scan, dim3(1), dim3(256), 0, stream_, V_);
     hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWave), 0, stream_, V_, 0, d_x32_.p, (float*)nullptr);
-    net_->forward(d_x32_.p, V_.batch_count, bcap_, d_pi_.p, d_v_.p);
+    if (cfg_.arena_mode) {   // evaluate(): Black's players ask network 0, White's network 1
+      const int half = bcap_ / 2;
+      net_->forward(d_x32_.p, V_.batch_count, half, d_pi_.p, d_v_.p);
+      net2_->forward(d_x32_.p + (size_t)half * V_.P * 32, V_.batch_count + 1, half, d_pi_.p + (size_t)half * V_.A,
+                     d_v_.p + half);
+    } else {
+      net_->forward(d_x32_.p, V_.batch_count, bcap_, d_pi_.p, d_v_.p);
+    }
     hipLaunchKernelGGL(k_post, dim3(V_.games), dim3(kWave), 0, stream_, V_);
   }
   AGZ_HIP(hipGetLastError());
@@ -338,32 +386,49 @@ void Engine::step(int nsteps) {
 
 int Engine::select_external() {
   hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream_, V_);
-  int32_t n = 0;
-  AGZ_HIP(hipMemcpyAsync(&n, V_.batch_count, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+  hipLaunchKernelGGL(cfg_.arena_mode ? k_scan_arena : k_scan, dim3(1), dim3(256), 0, stream_, V_);
+  int32_t n[2] = {0, 0};
+  AGZ_HIP(hipMemcpyAsync(n, V_.batch_count, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
-  external_batch_ = n;
-  return n;
+  external_batch_ = n[0];
+  external_batch2_ = cfg_.arena_mode ? n[1] : 0;
+  return external_batch_ + external_batch2_;
+}
+
+void Engine::arena_counts(int32_t* out) const {
+  out[0] = external_batch_;
+  out[1] = external_batch2_;
 }
 
 void Engine::leaf_features_external(float* feats_out) {
-  const int B = external_batch_;
-  if (B <= 0) return;
-  d_whcn_.ensure((size_t)bcap_ * 17 * V_.P);
+  const int B = external_batch_, B2 = external_batch2_;
+  if (B + B2 <= 0) return;
+  const size_t per = (size_t)17 * V_.P;
+  d_whcn_.ensure((size_t)bcap_ * per);
   hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWave), 0, stream_, V_, 0, (float*)nullptr, d_whcn_.p);
-  AGZ_HIP(hipMemcpyAsync(feats_out, d_whcn_.p, sizeof(float) * (size_t)B * 17 * V_.P, hipMemcpyDeviceToHost, stream_));
+  if (B) AGZ_HIP(hipMemcpyAsync(feats_out, d_whcn_.p, sizeof(float) * (size_t)B * per, hipMemcpyDeviceToHost, stream_));
+  // arena: the White players' rows follow the Black players' rows in the host buffer
+  if (B2) AGZ_HIP(hipMemcpyAsync(feats_out + (size_t)B * per, d_whcn_.p + (size_t)(bcap_ / 2) * per,
+                                 sizeof(float) * (size_t)B2 * per, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
 }
 
 void Engine::incorporate_external(const float* pi, const float* v) {
-  const int B = external_batch_;
+  const int B = external_batch_, B2 = external_batch2_;
   if (B > 0) {
     AGZ_HIP(hipMemcpyAsync(d_pi_.p, pi, sizeof(float) * (size_t)B * V_.A, hipMemcpyHostToDevice, stream_));
     AGZ_HIP(hipMemcpyAsync(d_v_.p, v, sizeof(float) * (size_t)B, hipMemcpyHostToDevice, stream_));
   }
+  if (B2 > 0) {
+    const size_t half = (size_t)bcap_ / 2;
+    AGZ_HIP(hipMemcpyAsync(d_pi_.p + half * V_.A, pi + (size_t)B * V_.A, sizeof(float) * (size_t)B2 * V_.A,
+                           hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipMemcpyAsync(d_v_.p + half, v + B, sizeof(float) * (size_t)B2, hipMemcpyHostToDevice, stream_));
+  }
   hipLaunchKernelGGL(k_post, dim3(V_.games), dim3(kWave), 0, stream_, V_);
   AGZ_HIP(hipStreamSynchronize(stream_));
   external_batch_ = 0;
+  external_batch2_ = 0;
 }
 
 void Engine::stats(agz_stats* out) {
@@ -562,7 +627,7 @@ void Engine::net_forward_positions(const int8_t* boards, const int8_t* deltas, c
   AGZ_HIP(hipMemcpyAsync(s_tp_.p, to_play, (size_t)B, hipMemcpyHostToDevice, stream_));
   AGZ_HIP(hipMemcpyAsync(d_count_.p, &B, sizeof(int32_t), hipMemcpyHostToDevice, stream_));
   launch_features_from_deltas(s_boards_.p, s_deltas_.p, s_i32a_.p, s_tp_.p, B, V_.N, s_f32a_.p, nullptr, stream_);
-  net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
+  net().forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
   AGZ_HIP(hipMemcpyAsync(pi_out, s_f32b_.p, sizeof(float) * (size_t)B * V_.A, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipMemcpyAsync(v_out, s_f32b_.p + (size_t)B * V_.A, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
@@ -579,7 +644,7 @@ void Engine::net_forward_features(const float* feats, int B, float* pi_out, floa
   AGZ_HIP(hipMemcpyAsync(d_whcn_.p, feats, sizeof(float) * (size_t)B * 17 * P, hipMemcpyHostToDevice, stream_));
   AGZ_HIP(hipMemcpyAsync(d_count_.p, &B, sizeof(int32_t), hipMemcpyHostToDevice, stream_));
   launch_whcn_to_x32(d_whcn_.p, B, V_.N, s_f32a_.p, stream_);
-  net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
+  net().forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
   AGZ_HIP(hipMemcpyAsync(pi_out, s_f32b_.p, sizeof(float) * (size_t)B * V_.A, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipMemcpyAsync(v_out, s_f32b_.p + (size_t)B * V_.A, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
@@ -616,12 +681,12 @@ void Engine::fill_synthetic_inputs(int B) {
 float Engine::time_forward(int B, int iters) {
   AGZ_REQUIRE(B > 0 && iters > 0, AGZ_BAD_ARGUMENT, "B and iters must be positive");
   fill_synthetic_inputs(B);
-  net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);   // warm-up
+  net().forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);   // warm-up
   hipEvent_t e0, e1;
   AGZ_HIP(hipEventCreate(&e0));
   AGZ_HIP(hipEventCreate(&e1));
   AGZ_HIP(hipEventRecord(e0, stream_));
-  for (int i = 0; i < iters; ++i) net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
+  for (int i = 0; i < iters; ++i) net().forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
   AGZ_HIP(hipEventRecord(e1, stream_));
   AGZ_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -635,7 +700,7 @@ float Engine::time_conv(int B, int iters) {
   AGZ_REQUIRE(B > 0 && iters > 0, AGZ_BAD_ARGUMENT, "B and iters must be positive");
   fill_synthetic_inputs(B);
   // one forward leaves real (post-ReLU, mixed-sign-weight) activations in the tower buffers
-  net_->forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
+  net().forward(s_f32a_.p, d_count_.p, B, s_f32b_.p, s_f32b_.p + (size_t)B * V_.A);
   net_->launch_tower_conv_once(d_count_.p, B);
   hipEvent_t e0, e1;
   AGZ_HIP(hipEventCreate(&e0));

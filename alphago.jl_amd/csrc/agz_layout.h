@@ -23,7 +23,8 @@ inline void fill_dims(View& V, const agz_config& c) {
   V.max_game_length = (V.P * 7) / 5;                      // mcts.jl:21
   V.maxd = V.max_game_length + 8;
   V.tau = ((V.P / 12) / 2) * 2;                           // mcts_play.jl:19
-  V.two_player = c.two_player_mode;
+  V.arena = c.arena_mode ? 1 : 0;
+  V.two_player = c.two_player_mode || c.arena_mode;       // evaluate(): both players are two_player_mode
   V.stagger = c.stagger_moves;
   V.cap = c.max_nodes_per_game > 0 ? c.max_nodes_per_game : 16 * c.num_readouts + 256;
   V.fin_cap = c.record_capacity_games > 0 ? c.record_capacity_games : 2 * c.games + 64;
@@ -68,7 +69,8 @@ inline void for_each_buffer(View& V, F&& f) {
   f(V.fin_pi, (size_t)V.fin_cap * mgl * V.A);
   f(V.fin_q, (size_t)V.fin_cap * mgl);
   f(V.counters, (size_t)CT_COUNT);
-  f(V.batch_count, (size_t)1);
+  f(V.batch_count, (size_t)2);
+  f(V.ar_hdr, (size_t)4 * (V.games / 2 + 1));
 }
 
 }  // namespace agz

@@ -878,10 +878,155 @@ AGZ_FN void game_select_phase(W& w, const View& V, Scratch& S, int g, int par) {
   w.count(&V.counters[CT_ROOTVISITS], (unsigned long long)(G.rootN - n_before));
 }
 
+// ---------------------------------------------------------------- evaluate() arena ----
+// neural_net.jl:103-158 for many games at once.  Slots come in pairs: slot 2i is the Black
+// player of game i (network 0), slot 2i+1 the White player (network 1), each with its own tree
+// (`black` / `white` MCTSPlayers, two_player_mode: arg-max picks, no noise, no pi).  The side to
+// move searches; when its budget is spent it moves at the END of k_post and publishes the move in
+// the pair's mailbox; the partner reads the mailbox at the START of the next k_pre, plays the same
+// move on its tree and takes over.  Writer and reader therefore always run in different kernel
+// launches: no intra-kernel communication, deterministic.
+
+template <class W>
+AGZ_FN void arena_finish(W& w, const View& V, Scratch& S, int g, bool emit, int winner, int was_resign) {
+  GameState& G = V.gs[g];
+  if (emit) {
+    // `result(black.root.position)` (:147) is the Tromp-Taylor result of the final position
+    load_board(w, V, S, node_index(V, g, G.root));
+    const float sc = area_score(w, V, S, G.komi);
+    game_finish(w, V, S, g, winner, was_resign, sc);
+  }
+  if (w.leader()) { G.phase = G_IDLE; G.arena_k = G.arena_k + 1; G.nleaves = 0; }
+  w.sync();
+}
+
+template <class W>
+AGZ_FN void arena_start(W& w, const View& V, Scratch& S, int g, uint64_t index) {
+  GameState& G = V.gs[g];
+  const int k = G.arena_k;
+  game_start(w, V, S, g, 2 * index + (uint64_t)(g & 1));
+  if (w.leader()) {
+    G.arena_k = k;
+    G.resign_disabled = 0;
+    G.resign_threshold = V.resign_threshold;     // MCTSPlayer default, evaluate passes none (:110-111)
+    if (g & 1) G.phase = G_ARENA_WAIT;
+    else { G.target = G.rootN + (float)V.R; G.phase = G_SEARCH; }     // :121-126, root not pre-expanded
+  }
+  w.sync();
+}
+
+// play the partner's move on this slot's tree: play_move!(inactive, move) (:137)
+template <class W>
+AGZ_FN bool arena_apply(W& w, const View& V, Scratch& S, int g, int a, float q) {
+  GameState& G = V.gs[g];
+  const long ri = node_index(V, g, G.root);
+  const int k = G.move_count;
+  if (k < V.max_game_length) {
+    w.for_each(V.A, [&](int i) { V.rec_pi[((long)g * V.max_game_length + k) * V.A + i] = 0.f; });
+    if (w.leader()) {
+      V.rec_moves[(long)g * V.max_game_length + k] = (int16_t)a;
+      V.rec_q[(long)g * V.max_game_length + k] = q;
+    }
+  }
+  w.sync();
+  int child = V.child[ri * V.AP + a];
+  if (child < 0) child = node_create_child(w, V, S, g, G.root, a);
+  if (child < 0) return false;
+  reroot(w, V, S, g, a, child);
+  if (w.leader()) { G.move_count = k + 1; G.nqs = k + 1; }
+  w.sync();
+  return true;
+}
+
+template <class W>
+AGZ_FN void arena_pre(W& w, const View& V, Scratch& S, int g) {
+  GameState& G = V.gs[g];
+  const int pair = g >> 1, npairs = V.games >> 1;
+  if (G.phase == G_MANUAL || G.phase == G_RETIRED) {
+    if (w.leader()) G.nleaves = 0;
+    w.sync();
+    return;
+  }
+  if (G.phase == G_IDLE) {
+    if (w.leader()) G.nleaves = 0;
+    w.sync();
+    const long long idx = (long long)pair + (long long)G.arena_k * npairs;    // both slots derive the same sequence
+    if (V.total_games > 0 && idx >= V.total_games) {
+      if (w.leader()) G.phase = G_RETIRED;
+      w.sync();
+      return;
+    }
+    arena_start(w, V, S, g, V.id_base + (uint64_t)idx * V.id_stride);
+  }
+  if (G.phase == G_ARENA_WAIT) {
+    if (w.leader()) G.nleaves = 0;
+    w.sync();
+    const int32_t* hdr = V.ar_hdr + 4 * pair;
+    const int hk = hdr[0], hply = hdr[1], hdone = hdr[2], hres = hdr[3];
+    if (hk != G.arena_k) return;                            // nothing published for this game yet
+    if (hply > G.move_count) {
+      const long pg = (long)(g ^ 1) * V.max_game_length + G.move_count;
+      const int a = V.rec_moves[pg];
+      const float q = V.rec_q[pg];
+      if (!arena_apply(w, V, S, g, a, q)) { arena_finish(w, V, S, g, false, 0, 0); return; }
+    } else if (!hdone) {
+      return;
+    }
+    if (hdone) {                                            // set_result!(inactive, ...) (:131,144)
+      if (w.leader()) { G.result = (hres & 3) - 1; G.was_resign = hres >> 2; }
+      w.sync();
+      arena_finish(w, V, S, g, false, 0, 0);
+      return;
+    }
+    if (w.leader()) { G.target = G.rootN + (float)V.R; G.phase = G_SEARCH; }     // :121-126
+    w.sync();
+  }
+  if (G.phase == G_SEARCH) game_select_phase(w, V, S, g, V.par);
+}
+
+// the active player's budget is spent: :128-146
+template <class W>
+AGZ_FN void arena_move_phase(W& w, const View& V, Scratch& S, int g) {
+  GameState& G = V.gs[g];
+  const int pair = g >> 1;
+  int32_t* hdr = V.ar_hdr + 4 * pair;
+  const long ri = node_index(V, g, G.root);
+  const NodeMeta rm = V.meta[ri];
+  const float q = G.rootW / (1.0f + G.rootN);
+  const float qp = q * (float)rm.to_play;
+  if ((double)qp < G.resign_threshold) {                    // should_resign(active) (:129-133)
+    const int winner = -rm.to_play;
+    if (w.leader()) { hdr[0] = G.arena_k; hdr[1] = G.move_count; hdr[2] = 1; hdr[3] = (winner + 1) | 4; }
+    w.sync();
+    arena_finish(w, V, S, g, true, winner, 1);
+    return;
+  }
+  int a = V.P;
+  if (pick_move(w, V, S, g, &a) != AGZ_OK) a = V.P;
+  if (!arena_apply(w, V, S, g, a, q)) {
+    if (w.leader()) { hdr[0] = G.arena_k; hdr[1] = G.move_count; hdr[2] = 1; hdr[3] = 1; }
+    w.sync();
+    arena_finish(w, V, S, g, true, 0, 0);
+    return;
+  }
+  w.count(&V.counters[CT_POSITIONS], 1);
+  if (node_is_done(V, g, G.root)) {                         // :140-145
+    load_board(w, V, S, node_index(V, g, G.root));
+    const int winner = result_of(area_score(w, V, S, G.komi));
+    if (w.leader()) { hdr[0] = G.arena_k; hdr[1] = G.move_count; hdr[2] = 1; hdr[3] = winner + 1; }
+    w.sync();
+    arena_finish(w, V, S, g, true, winner, 0);
+    return;
+  }
+  if (w.leader()) { hdr[0] = G.arena_k; hdr[1] = G.move_count; hdr[2] = 0; hdr[3] = 0; G.phase = G_ARENA_WAIT; }
+  w.sync();
+}
+
 // Phase A+B of a self-play step for game slot g: lifecycle, per-move phase, select.
 template <class W>
 AGZ_FN void game_pre(W& w, const View& V, Scratch& S, int g) {
   GameState& G = V.gs[g];
+  if (V.arena && G.phase != G_MANUAL) { arena_pre(w, V, S, g); return; }
   if (G.phase == G_MANUAL || G.phase == G_RETIRED) {
     if (w.leader() && G.phase == G_RETIRED) G.nleaves = 0;
     w.sync();
@@ -920,6 +1065,10 @@ template <class W>
 AGZ_FN void game_post(W& w, const View& V, Scratch& S, int g) {
   GameState& G = V.gs[g];
   const int nl = G.nleaves;
+  if (V.arena && G.phase == G_SEARCH && nl <= 0) {          // a select phase of terminal leaves only
+    if (!(G.rootN < G.target)) arena_move_phase(w, V, S, g);
+    return;
+  }
   if (nl <= 0 || (G.phase != G_SEARCH && G.phase != G_INIT_WAIT && G.phase != G_MANUAL)) return;
   const float n_before = G.rootN;
   for (int k = 0; k < nl; ++k) {
@@ -945,6 +1094,7 @@ AGZ_FN void game_post(W& w, const View& V, Scratch& S, int g) {
   }
   if (w.leader()) G.nleaves = 0;
   w.sync();
+  if (V.arena && G.phase == G_SEARCH && !(G.rootN < G.target)) arena_move_phase(w, V, S, g);
 }
 
 // Feature planes of one leaf slot into the stem-input layout [P][32] (features.jl:3-26)

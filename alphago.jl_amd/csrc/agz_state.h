@@ -17,7 +17,10 @@ namespace agz {
 constexpr int kMaxPar = 64;        // upper bound on parallel_readouts
 constexpr int kWave = 64;
 
-enum GamePhase : int32_t { G_IDLE = 0, G_INIT = 1, G_INIT_WAIT = 2, G_SEARCH = 3, G_MANUAL = 4, G_RETIRED = 5 };
+enum GamePhase : int32_t {
+  G_IDLE = 0, G_INIT = 1, G_INIT_WAIT = 2, G_SEARCH = 3, G_MANUAL = 4, G_RETIRED = 5,
+  G_ARENA_WAIT = 6    // arena: the partner slot (other colour, other network) is to move
+};
 
 enum NodeFlags : uint8_t { NF_EXPANDED = 1, NF_DONE = 2, NF_ALLOC = 4 };
 
@@ -56,7 +59,7 @@ struct GameState {
   int32_t was_resign;
   int32_t nodes_used;
   int32_t short_first;       // bench stagger: the first search of this game has a shortened budget
-  int32_t pad;
+  int32_t arena_k;           // arena: games this slot has finished (= local index of the current one)
 };
 
 enum Counter : int {
@@ -68,6 +71,7 @@ struct View {
   // dimensions
   int N, P, PP, A, AP, LW, cap, games, par, maxd;
   int R, max_game_length, tau, two_player, stagger;
+  int arena;           // evaluate() arena: slots 2i / 2i+1 are Black's / White's player of one game
   int fin_cap;
   int64_t total_games;
   uint64_t seed, id_base, id_stride;
@@ -102,7 +106,8 @@ struct View {
   float* fin_q;
   // counters / batch
   unsigned long long* counters;
-  int32_t* batch_count;   // device scalar: leaves in this step's batch
+  int32_t* batch_count;   // device scalars: leaves in this step's batch ([0]; arena: [0] Black's, [1] White's players)
+  int32_t* ar_hdr;        // arena mailbox [games/2][4]: {local game index, plies played, done, -}
   const float* pi;        // [batch][A]
   const float* v;         // [batch]
 };

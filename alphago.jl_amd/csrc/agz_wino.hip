@@ -72,39 +72,56 @@ __device__ __forceinline__ void bt5(float x0, float x1, float x2, float x3, floa
   r[4] = 2.f * x1 - x2 - 2.f * x3 + x4;
 }
 
-// grid = tile blocks; 512 threads = 64 tiles x 8 channel pairs (= 4 consecutive stages x 2 halves):
-// the eight lanes of a tile read one 64-byte run of every patch point; loops over 16 stage groups.
-// Two channels per thread keep the kernel at ~120 VGPRs (4 waves/SIMD) -- it is HBM-bound.
-__global__ __launch_bounds__(512) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
+// grid = 2 x tile blocks (32-tile halves); 256 threads = 32 tiles x 8 channel pairs (= 4 consecutive
+// stages x 2 halves): the eight lanes of a tile read one 64-byte run of every patch point.  A pass
+// covers 16 channels = 4 stages; the transformed values go to an LDS copy of this half-block's part
+// of the four stage images (4 x 13 chunks of 32 rows x 32 B = 1 KB) and leave for HBM as whole
+// 1 KB runs, 16 B per lane -- written straight from registers they were 16-byte fragments spread
+// over four stage images, and the kernel sat at 3.8 TB/s.  Stage images are skewed by {0,4,32,36}
+// dwords in LDS so that the four stage lanes of a tile hit different banks.
+template <int TPB, bool NT>   // tiles per workgroup: 32 (8 lanes = 64 B per patch point) or 16 (16 lanes = one 128 B line)
+__global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T) {
+  constexpr int LPT = 256 / TPB;             // lanes per tile
+  constexpr int SP = LPT / 2;                // stages per pass
+  constexpr int CH = TPB * 8;                // dwords per chunk (TPB rows of one row pair)
+  constexpr int IMG = 13 * CH + 64;          // LDS stride between the stage images of a pass
+  constexpr int CPR = 256 / (TPB * 2);       // chunks copied out per round
+  __shared__ __attribute__((aligned(16))) float img[SP * IMG];
+  auto skew = [](int sl) { return TPB == 32 ? (sl & 1) * 4 + (sl >> 1) * 32 : (sl & 1) * 4 + (sl >> 1) * 16; };
   const int P = N * N, TT = T * T;
   const long Mt = (long)(*d_count) * TT;
-  const int tb = blockIdx.x;
-  if ((long)tb * WT >= Mt) return;
-  const int hs = threadIdx.x & 7, h = hs & 1, sl = hs >> 1;
-  const int tl = threadIdx.x >> 3;                  // tile within the block
-  const long tile = (long)tb * WT + tl;
+  constexpr int PARTS = WT / TPB;
+  const int tb = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
+  if ((long)tb * WT + part * TPB >= Mt) return;
+  const int hs = threadIdx.x % LPT, h = hs & 1, sl = hs >> 1;
+  const int tl = threadIdx.x / LPT;                 // tile within this part
+  const int row = part * TPB + tl;                  // row of the 64-row stage image
+  const long tile = (long)tb * WT + row;
   const bool live = tile < Mt;
   const int b = live ? (int)(tile / TT) : 0, t = live ? (int)(tile % TT) : 0;
   const int ti = t / T, tj = t % T;
-  long off[25];
+  int off[25];                                      // element offsets < 2^31 (8192 x 361 x 256 = 7.6e8)
 #pragma unroll
   for (int u = 0; u < 5; ++u)
 #pragma unroll
     for (int v = 0; v < 5; ++v) {
       const int pi = 3 * ti - 1 + u, pj = 3 * tj - 1 + v;
       const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
-      off[u * 5 + v] = ok ? ((long)b * P + pi + (long)N * pj) * kC : -1;
+      off[u * 5 + v] = ok ? (b * P + pi + N * pj) * kC : -1;
     }
-  const int rot = wino_rot(tl);
-  float* img = vimg + (long)tb * WNS * A_STAGE + (long)tl * 8;
-  for (int sg = 0; sg < WNS / 4; ++sg) {
-    const int st = sg * 4 + sl;
+  const int rot = wino_rot(row);
+  float* mine = img + sl * IMG + skew(sl) + tl * 8;
+  // the unused plane slot 25 (second half of pair 12) is copied out with the rest: keep it finite
+  *reinterpret_cast<float2*>(mine + 12 * CH + 2 * ((2 + h + rot) & 3)) = make_float2(0.f, 0.f);
+  float* gdst = vimg + (long)tb * WNS * A_STAGE + part * CH;
+  const int cq = threadIdx.x / (TPB * 2), cl = threadIdx.x % (TPB * 2);
+  for (int sg = 0; sg < WNS / SP; ++sg) {
+    const int st = sg * SP + sl;
     float2 d[25];
 #pragma unroll
     for (int q = 0; q < 25; ++q)
       d[q] = off[q] >= 0 ? *reinterpret_cast<const float2*>(x + off[q] + st * WK + 2 * h) : make_float2(0.f, 0.f);
-    float* dst = img + (long)st * A_STAGE;
     // V = B^T d B, one channel component at a time
     float tx[25], ty[25];
 #pragma unroll
@@ -117,6 +134,7 @@ __global__ __launch_bounds__(512) void k_wino_in(const float* __restrict__ x, fl
 #pragma unroll
       for (int i = 0; i < 5; ++i) ty[i * 5 + v] = r[i];
     }
+    if (sg) __syncthreads();                        // the previous pass has left the LDS image
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       float rx[5], ry[5];
@@ -125,9 +143,18 @@ __global__ __launch_bounds__(512) void k_wino_in(const float* __restrict__ x, fl
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         const int xi = i * 5 + j;
-        *reinterpret_cast<float2*>(dst + (long)(xi >> 1) * WT * 8 + 2 * ((2 * (xi & 1) + h + rot) & 3)) =
-            make_float2(rx[j], ry[j]);
+        *reinterpret_cast<float2*>(mine + (xi >> 1) * CH + 2 * ((2 * (xi & 1) + h + rot) & 3)) = make_float2(rx[j], ry[j]);
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 13; ++r) {
+      const int c = r * CPR + cq, s4 = c / 13, q = c % 13;     // chunk c = (stage s4 of this pass, row pair q)
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(img + s4 * IMG + skew(s4) + q * CH + cl * 4);
+      f32x4* gp = reinterpret_cast<f32x4*>(gdst + (long)(sg * SP + s4) * A_STAGE + q * (WT * 8) + cl * 4);
+      if (NT) __builtin_nontemporal_store(v, gp);     // V is 2.8x the activations and is read back much later
+      else *gp = v;
     }
   }
 }
@@ -394,7 +421,7 @@ void launch_wino_conv(const float* x, float* vimg, const float* uimg, const floa
                       const float* res, float* y, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
   const int T = (N + 2) / 3;
   const int blocks = (int)(((long)bcap * T * T + WT - 1) / WT);
-  hipLaunchKernelGGL(k_wino_in, dim3(blocks), dim3(512), 0, s, x, vimg, d_count, N, T);
+  hipLaunchKernelGGL((k_wino_in<32, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
   static const int dbg = getenv("AGZ_WINO_DEBUG") ? atoi(getenv("AGZ_WINO_DEBUG")) : 0;   // timing experiments only
   auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : dbg == 3 ? k_wino_gemm<3> : dbg == 4 ? k_wino_gemm<4> : dbg == 5 ? k_wino_gemm<5> : k_wino_gemm<0>;
   const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm

@@ -196,10 +196,29 @@ class Engine:
         pi, v = _f32(pi), _f32(v)
         self._ck(self.L.agz_selfplay_incorporate(self.h, _p(pi, C.c_float), _p(v, C.c_float)))
 
-    def step_external(self, network):
-        """one step with a caller-supplied network(feats [B,17P]) -> (pi [B,A], v [B])"""
+    def net_select(self, which):
+        """arena_mode: address network 0 (Black's) or 1 (White's) with the weight / forward calls"""
+        self._ck(self.L.agz_net_select(self.h, which))
+
+    def arena_counts(self):
+        out = (C.c_int32 * 2)()
+        self._ck(self.L.agz_arena_counts(self.h, out))
+        return int(out[0]), int(out[1])
+
+    def step_external(self, network, white_network=None):
+        """one step with a caller-supplied network(feats [B,17P]) -> (pi [B,A], v [B]); in arena
+        mode `network` answers the Black players' leaves and `white_network` the White players'"""
         n = self.select()
-        if n > 0:
+        if n > 0 and white_network is not None:
+            n0, n1 = self.arena_counts()
+            feats = self.leaf_features(n)
+            pi, v = np.zeros((n, self.A), np.float32), np.zeros(n, np.float32)
+            if n0:
+                pi[:n0], v[:n0] = network(feats[:n0])
+            if n1:
+                pi[n0:], v[n0:] = white_network(feats[n0:])
+            self.incorporate(pi, v)
+        elif n > 0:
             pi, v = network(self.leaf_features(n))
             self.incorporate(pi, v)
         else:

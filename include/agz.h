@@ -72,7 +72,8 @@ typedef struct {
   int32_t external_network;        /* 1: pi/v are supplied by the caller (duck-typed network) */
   int32_t stagger_moves;           /* bench only: random opening prefix of up to this many moves */
   int32_t record_capacity_games;   /* finished-game record slots kept on the device; 0 = auto */
-  int32_t reserved1;
+  int32_t arena_mode;              /* 1: evaluate() arena -- slots 2i / 2i+1 are the Black / White player of one
+                                    * game with networks 0 / 1 (agz_net_select); `games` must be even */
 } agz_config;
 
 int32_t agz_version(void);
@@ -103,6 +104,10 @@ agz_status agz_net_set_weights(agz_engine* e, int32_t layer, int32_t kind, const
 int64_t agz_net_param_count(const agz_engine* e, int32_t layer, int32_t kind);
 /* read a parameter back in the layout it was set in (save_model, train.jl:14-35) */
 agz_status agz_net_get_weights(agz_engine* e, int32_t layer, int32_t kind, float* out, int64_t count);
+/* evaluate(env, black_net, white_net) neural_net.jl:103-158 needs two networks in one engine
+ * (arena_mode): `which` = 0 (Black's, the default) or 1 (White's) selects the network that the
+ * agz_net_set_weights / get_weights / init_synthetic / forward* calls after it address. */
+agz_status agz_net_select(agz_engine* e, int32_t which);
 /* Flux-default-equivalent init from the draw stream (glorot-uniform, zero bias, BN identity,
  * eps 1e-5) -- the synthetic weights of SURVEY.md 8d */
 agz_status agz_net_init_synthetic(agz_engine* e, uint64_t seed);
@@ -197,6 +202,14 @@ agz_status agz_records_game(agz_engine* e, int64_t k, int16_t* moves, float* pis
 agz_status agz_records_packed_size(agz_engine* e, int64_t* nbytes_out);
 agz_status agz_records_export_packed(agz_engine* e, void* dst, int64_t capacity, int32_t is_device);
 agz_status agz_records_clear(agz_engine* e);
+/* arena_mode with external_network: after agz_selfplay_select, counts_out[0] leaves belong to Black
+ * players (network 0) and counts_out[1] to White players (network 1); agz_selfplay_leaf_features
+ * and agz_selfplay_incorporate order the rows [Black players' | White players'].  A finished
+ * arena game is one record: game_id = 2*game + colour of the player that ended it, moves, qs =
+ * Q(root) of the mover, pis zero (two_player_mode records none, mcts_play.jl:33-36), result = what
+ * set_result! stored, final_score = score(final position) -- evaluate's tally (:147) is
+ * final_score > 0, also for resigned games. */
+agz_status agz_arena_counts(agz_engine* e, int32_t* counts_out);
 /* replay_position(pos, result) board.jl:557-578 on the device: rebuild the feature tensors of
  * every position of record k: out float[num_moves][N*N*17] (WHC per position) */
 agz_status agz_records_features(agz_engine* e, int64_t k, float* out);

@@ -169,6 +169,26 @@ OPlayer* or_selfplay(int N, or_net_fn net, void* net_ctx, int num_readouts, uint
 OPlayer* or_selfplay_ex(int N, or_net_fn net, void* net_ctx, int num_readouts, uint64_t seed,
                         uint64_t game, int max_moves, double threshold, double disable_fraction);
 
+/* ---- evaluate, src/neural_net.jl:103-158: ONE game of the two-network arena ----
+ * black_net always plays Black, white_net White; both players are two_player_mode MCTSPlayers
+ * (tau_threshold = -1: pick_move is always the arg-max; no pi recording; no Dirichlet noise) with
+ * their own trees, advanced with the same moves.  Draw streams: Black's player is keyed
+ * (seed, 2*game), White's (seed, 2*game+1).  `black_won` is the reference's tally
+ * `result(black.root.position) == BLACK` (:147) -- the Tromp-Taylor result of the final position,
+ * also for resigned games. */
+typedef struct {
+  int num_moves;       /* moves played */
+  int result;          /* what set_result! stored: winner (+1 Black / -1 White / 0) */
+  int was_resign;
+  int black_won;       /* :147 */
+  float final_score;   /* score(black.root.position) */
+  uint64_t evals_black, evals_white;
+} OEvalGame;
+void or_evaluate_game(int N, or_net_fn black_net, void* black_ctx, or_net_fn white_net, void* white_ctx,
+                      int num_readouts, double resign_threshold, uint64_t seed, uint64_t game,
+                      int16_t* moves_out /* >= max_game_length, may be NULL */,
+                      float* qs_out /* Q(root) of the mover before each move, may be NULL */, OEvalGame* out);
+
 /* ---- network, src/neural_net.jl:13-33,57-73 + src/resnet.jl:11-32 ---- */
 typedef struct ONet ONet;
 ONet* or_net_new(int N, int tower_height);

@@ -503,6 +503,53 @@ OPlayer* or_selfplay(int N, or_net_fn net, void* net_ctx, int num_readouts, uint
   return or_selfplay_ex(N, net, net_ctx, num_readouts, seed, game, max_moves, -0.9, 0.05);
 }
 
+/* evaluate(), neural_net.jl:103-158, the body of `for i = 1:num_games` */
+void or_evaluate_game(int N, or_net_fn black_net, void* black_ctx, or_net_fn white_net, void* white_ctx,
+                      int num_readouts, double resign_threshold, uint64_t seed, uint64_t game,
+                      int16_t* moves_out, float* qs_out, OEvalGame* out) {
+  OPlayer* black = or_player_new(N, black_net, black_ctx, num_readouts, 1, resign_threshold, seed, 2 * game);
+  OPlayer* white = or_player_new(N, white_net, white_ctx, num_readouts, 1, resign_threshold, seed, 2 * game + 1);
+  or_player_initialize_game(black, NULL);
+  or_player_initialize_game(white, NULL);
+  int A = black->env.A;
+  int num_move = 0;
+  memset(out, 0, sizeof(*out));
+  for (;;) {
+    OPlayer* active = (num_move % 2) ? white : black;      /* :118-119 */
+    OPlayer* inactive = (num_move % 2) ? black : white;
+    float current = or_node_N(active->root);                /* :121-126 */
+    while (or_node_N(active->root) < current + (float)active->num_readouts) or_player_tree_search(active, 8);
+    if (or_player_should_resign(active)) {                  /* :129-133 */
+      int winner = -active->root->pos.to_play;
+      or_player_set_result(active, winner, 1);
+      or_player_set_result(inactive, winner, 1);
+      out->was_resign = 1;
+      break;
+    }
+    int a = -1;
+    if (or_player_pick_move(active, &a) != OR_OK) a = A - 1;
+    if (qs_out) qs_out[num_move] = or_node_Q(active->root);
+    or_player_play_move(active, a);                         /* :135-137 */
+    or_player_play_move(inactive, a);
+    if (moves_out) moves_out[num_move] = (int16_t)a;
+    num_move++;
+    if (or_node_is_done(&active->env, active->root)) {      /* :140-145 */
+      int winner = or_result(&active->root->pos);
+      or_player_set_result(active, winner, 0);
+      or_player_set_result(inactive, winner, 0);
+      break;
+    }
+  }
+  out->num_moves = num_move;
+  out->result = black->result;
+  out->final_score = or_score(&black->root->pos);
+  out->black_won = or_result(&black->root->pos) == 1;      /* :147 */
+  out->evals_black = black->evals;
+  out->evals_white = white->evals;
+  or_player_free(black);
+  or_player_free(white);
+}
+
 /* ---- thin exports of the draw-stream header for tests/test_draws.py ---- */
 uint64_t or_draw_u64(uint64_t seed, uint64_t game, uint32_t move, uint32_t site, uint64_t idx) {
   return agz_draw_u64(seed, game, move, site, idx);

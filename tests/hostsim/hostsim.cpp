@@ -94,7 +94,11 @@ void hs_start(void* h, int64_t total_games) {
   Sim* s = (Sim*)h;
   s->V.total_games = total_games;
   memset(s->V.counters, 0, sizeof(unsigned long long) * agz::CT_COUNT);
-  for (int g = 0; g < s->V.games; ++g) s->V.gs[g].phase = agz::G_IDLE;
+  memset(s->V.ar_hdr, 0, sizeof(int32_t) * 4 * (s->V.games / 2 + 1));
+  for (int g = 0; g < s->V.games; ++g) {
+    memset(&s->V.gs[g], 0, sizeof(agz::GameState));
+    s->V.gs[g].phase = agz::G_IDLE;
+  }
 }
 
 // phase A+B for every slot, then the prefix scan that assigns batch rows
@@ -103,6 +107,19 @@ int hs_pre(void* h) {
   SimWave w;
   for (int g = 0; g < s->V.games; ++g) agz::game_pre(w, s->V, s->S, g);
   int base = 0;
+  if (s->V.arena) {   // rows: [Black players' leaves | White players' leaves]
+    for (int c = 0; c < 2; ++c) {
+      const int before = base;
+      for (int g = c; g < s->V.games; g += 2) {
+        s->V.gs[g].leaf_base = base;
+        base += s->V.gs[g].nleaves;
+      }
+      s->V.batch_count[c] = base - before;
+    }
+    s->batch = base;
+    s->V.counters[agz::CT_STEPS] += 1;
+    return base;
+  }
   for (int g = 0; g < s->V.games; ++g) {
     s->V.gs[g].leaf_base = base;
     base += s->V.gs[g].nleaves;
@@ -128,6 +145,11 @@ void hs_post(void* h, const float* pi, const float* v) {
   s->V.pi = pi;
   s->V.v = v;
   for (int g = 0; g < s->V.games; ++g) agz::game_post(w, s->V, s->S, g);
+}
+
+void hs_arena_counts(void* h, int32_t* out) {
+  out[0] = ((Sim*)h)->V.batch_count[0];
+  out[1] = ((Sim*)h)->V.batch_count[1];
 }
 
 void hs_counters(void* h, unsigned long long* out) {

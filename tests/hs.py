@@ -20,7 +20,7 @@ class AgzConfig(C.Structure):
         ("resign_disable_fraction", C.c_double),
         ("seed", C.c_uint64), ("game_id_base", C.c_uint64), ("game_id_stride", C.c_uint64),
         ("max_nodes_per_game", C.c_int32), ("device", C.c_int32), ("external_network", C.c_int32),
-        ("stagger_moves", C.c_int32), ("record_capacity_games", C.c_int32), ("reserved1", C.c_int32),
+        ("stagger_moves", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
     ]
 
 
@@ -101,6 +101,7 @@ def lib():
         "hs_create": (vp, [P(AgzConfig)]), "hs_destroy": (None, [vp]), "hs_dims": (None, [vp, P(C.c_int32)]),
         "hs_start": (None, [vp, C.c_int64]), "hs_pre": (i, [vp]), "hs_leaf_features": (None, [vp, P(f)]),
         "hs_post": (None, [vp, P(f), P(f)]), "hs_counters": (None, [vp, P(C.c_ulonglong)]),
+        "hs_arena_counts": (None, [vp, P(C.c_int32)]),
         "hs_live_games": (i, [vp]), "hs_records_count": (C.c_long, [vp]),
         "hs_record_header": (None, [vp, C.c_long, P(GameHeader)]),
         "hs_record_game": (None, [vp, C.c_long, P(C.c_int16), P(f), P(f)]),
@@ -163,14 +164,27 @@ class Sim:
     def start(self, total_games):
         self.L.hs_start(self.h, total_games)
 
-    def step(self, net):
-        """one self-play step; net(feats [B,17*P] float32) -> (pi [B,A], v [B])"""
+    def step(self, net, white_net=None):
+        """one self-play step; net(feats [B,17*P] float32) -> (pi [B,A], v [B]).  Arena mode:
+        `net` answers the Black players' leaves, `white_net` the White players'."""
         B = self.L.hs_pre(self.h)
         if B == 0:
+            if white_net is not None:      # a step may consist of terminal leaves only: moves happen in post
+                z = np.zeros((1, self.A), np.float32)
+                self.L.hs_post(self.h, pf(z), pf(np.zeros(1, np.float32)))
             return 0
         feats = np.zeros((B, 17 * self.P), np.float32)
         self.L.hs_leaf_features(self.h, pf(feats))
-        pi, v = net(feats)
+        if white_net is not None:
+            cnt = (C.c_int32 * 2)()
+            self.L.hs_arena_counts(self.h, cnt)
+            pi, v = np.zeros((B, self.A), np.float32), np.zeros(B, np.float32)
+            if cnt[0]:
+                pi[:cnt[0]], v[:cnt[0]] = net(feats[:cnt[0]])
+            if cnt[1]:
+                pi[cnt[0]:], v[cnt[0]:] = white_net(feats[cnt[0]:])
+        else:
+            pi, v = net(feats)
         pi = np.ascontiguousarray(pi, np.float32)
         v = np.ascontiguousarray(v, np.float32)
         self.L.hs_post(self.h, pf(pi), pf(v))

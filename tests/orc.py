@@ -47,6 +47,11 @@ class OEnv(C.Structure):
                 ("dirichlet_alpha", C.c_float), ("c_puct", C.c_double), ("noise_weight", C.c_double)]
 
 
+class OEvalGame(C.Structure):
+    _fields_ = [("num_moves", C.c_int), ("result", C.c_int), ("was_resign", C.c_int), ("black_won", C.c_int),
+                ("final_score", C.c_float), ("evals_black", C.c_uint64), ("evals_white", C.c_uint64)]
+
+
 class ODraw(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("game", C.c_uint64), ("move", C.c_uint32), ("sel", C.c_uint32)]
 
@@ -142,6 +147,7 @@ def lib():
         "or_player_extract_data": (i, [vp, P(OPos), P(f), P(i)]),
         "or_selfplay": (vp, [i, NET_FN, vp, i, u64, u64, i]),
         "or_selfplay_ex": (vp, [i, NET_FN, vp, i, u64, u64, i, d, d]),
+        "or_evaluate_game": (None, [i, NET_FN, vp, NET_FN, vp, i, d, u64, u64, P(C.c_int16), P(f), P(OEvalGame)]),
         "or_net_new": (vp, [i, i]),
         "or_net_free": (None, [vp]),
         "or_net_set": (i, [vp, i, i, P(f), C.c_int64]),
