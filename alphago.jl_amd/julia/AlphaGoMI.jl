@@ -78,11 +78,12 @@ function Engine(; board_size = 19, tower_height = 19, games = 1, num_readouts = 
                 dirichlet_noise_weight = 0.25, resign_threshold = -0.9,
                 resign_disable_fraction = 0.05, seed = 0, game_id_base = 0, game_id_stride = 1,
                 max_nodes_per_game = 0, device = 0, external_network = false,
-                record_capacity_games = 0)
+                record_capacity_games = 0, arena_mode = false)
   cfg = AgzConfig(board_size, tower_height, games, num_readouts, parallel_readouts,
                   two_player_mode ? 1 : 0, komi, 0f0, c_puct, dirichlet_noise_weight,
                   resign_threshold, resign_disable_fraction, seed, game_id_base, game_id_stride,
-                  max_nodes_per_game, device, external_network ? 1 : 0, 0, record_capacity_games, 0)
+                  max_nodes_per_game, device, external_network ? 1 : 0, 0, record_capacity_games,
+                  arena_mode ? 1 : 0)
   h = Ref{Ptr{Cvoid}}(C_NULL)
   st = ccall((:agz_engine_create, libagz), Int32, (Ref{AgzConfig}, Ref{Ptr{Cvoid}}), cfg, h)
   st == AGZ_OK || error("agz_engine_create: " *
@@ -427,6 +428,55 @@ function copy_weights!(dst::Engine, src::Engine)
                      dst.handle, l, k, buf, n))
   end
   dst
+end
+
+# ------------------------------------------------------------------ evaluate
+# evaluate(env, black_net, white_net; num_games, ro), src/neural_net.jl:103-158: both networks live
+# in one arena_mode engine (network 0 = Black's, 1 = White's), every game is a pair of slots, all
+# games run concurrently.  Black's tally is `result(black.root.position) == BLACK` (:147), i.e.
+# final_score > 0, also for resigned games.
+function evaluate(env::GoEnv, black_net::NeuralNet, white_net::NeuralNet; num_games = 400, ro = 800,
+                  verbose::Bool = false, seed = 0, pairs::Int = min(num_games, 512))
+  @assert black_net.tower_height == white_net.tower_height
+  e = Engine(board_size = env.N, tower_height = black_net.tower_height, games = 2 * pairs, num_readouts = ro,
+             seed = seed, record_capacity_games = num_games + 8, arena_mode = true)
+  copy_weights!(e, black_net.engine)
+  check(e, ccall((:agz_net_select, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, 1))
+  copy_weights!(e, white_net.engine)
+  check(e, ccall((:agz_net_select, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, 0))
+  check(e, ccall((:agz_selfplay_start, libagz), Int32, (Ptr{Cvoid}, Int64), e.handle, num_games))
+  while ccall((:agz_records_count, libagz), Int64, (Ptr{Cvoid},), e.handle) < num_games
+    check(e, ccall((:agz_selfplay_step, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, 16))
+  end
+  games_won = 0
+  for k in 0:num_games-1
+    h = Ref{AgzGameHeader}()
+    check(e, ccall((:agz_records_header, libagz), Int32, (Ptr{Cvoid}, Int64, Ref{AgzGameHeader}), e.handle, k, h))
+    games_won += h[].final_score > 0
+  end
+  verbose && print("Won $games_won / $num_games. Win rate: $(games_won/num_games). ")
+  return games_won / num_games ≥ 0.55
+end
+
+# ------------------------------------------------------------------ replay batches
+# get_replay_batch(pos_buffer, π_buffer, res_buffer; batch_size), src/train.jl:4-12, with the
+# positions kept as move lists: `games[g]` is a GameRecord, a sample is (g, ply) with ply = 0 the
+# empty board.  Returns the N x N x 17 x B feature tensor get_feats would build, π (A x B), results.
+function get_replay_batch(e::Engine, env::GoEnv, games::Vector{GameRecord}, samples::Vector{Tuple{Int,Int}})
+  used = sort(unique(first.(samples)))
+  offs = Dict{Int,Int32}(); moves = Int16[]
+  for g in used
+    offs[g] = length(moves)
+    append!(moves, Int16.(games[g].moves .- 1))
+  end
+  B = length(samples)
+  off = Int32[offs[g] for (g, _) in samples]; ply = Int32[j for (_, j) in samples]
+  feats = zeros(Float32, env.N, env.N, 17, B)
+  check(e, ccall((:agz_replay_features, libagz), Int32,
+                 (Ptr{Cvoid}, Ptr{Int16}, Int64, Ptr{Int32}, Ptr{Int32}, Int32, Ptr{Float32}, Int32),
+                 e.handle, moves, length(moves), off, ply, B, feats, 0))
+  π = hcat((games[g].searches_π[j + 1] for (g, j) in samples)...)
+  feats, π, [games[g].result for (g, _) in samples]
 end
 
 end # module

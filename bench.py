@@ -228,7 +228,7 @@ def main():
                 "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
                 "flop_per_launch_avg": conv_flop / max(conv_n, 1),
                 # what the MFMA pipe actually executes: 25 multiplies per 3x3 output tile and (cin, cout)
-                "executed_flop_per_launch_avg": conv_flop * wino_ratio,
+                "executed_flop_per_launch_avg": conv_flop * wino_ratio / max(conv_n, 1),
                 "executed_frac": (conv_flop * wino_ratio / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
             },
         }
