@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--stagger", type=int, default=60, help="random opening prefix (moves) so games are at mixed stages")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-device-test", action="store_true",
+                    help="testing only: every rank uses cuda:0 and gloo, to exercise the multi-rank code path on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -137,12 +139,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if args.single_device_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    rdev = "cuda"          # where the cross-rank reductions of the two scalars live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.single_device_test:
+            dist.init_process_group("gloo")
+            rdev = "cpu"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     N, tower, R = args.board, args.tower, args.readouts
     eng = ag.Engine(board_size=N, tower_height=tower, games=args.games, num_readouts=R, parallel_readouts=8,
@@ -183,11 +192,11 @@ def main():
     d = {k: s1[k] - s0[k] for k in ("positions", "evals", "duplicate_evals", "terminal_visits", "root_visits",
                                     "games_finished", "steps")}
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         c = torch.tensor([d["positions"], d["evals"], d["root_visits"], d["games_finished"]], dtype=torch.float64,
-                         device="cuda")
+                         device=rdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         d["positions"], d["evals"], d["root_visits"], d["games_finished"] = [float(x) for x in c.tolist()]
     if s1["pool_exhausted"]:
