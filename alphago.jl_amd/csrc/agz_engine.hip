@@ -61,6 +61,18 @@ struct HipWave {
     return v;
   }
   __device__ __forceinline__ bool any(bool v) const { return __any(v) != 0; }
+  // append every get(i) >= 0, i ascending, to a downward stack (base[--sp]); returns the new sp
+  template <class F>
+  __device__ __forceinline__ int push_desc(int n, F get, int32_t* base, int sp) const {
+    for (int b = 0; b < n; b += kWave) {
+      const int i = b + lane;
+      const int c = i < n ? get(i) : -1;
+      const unsigned long long mask = __ballot(c >= 0);
+      if (c >= 0) base[sp - 1 - __popcll(mask & ((1ull << lane) - 1ull))] = c;
+      sp -= __popcll(mask);
+    }
+    return sp;
+  }
   __device__ __forceinline__ void amin(int32_t* p, int v) const { atomicMin(p, v); }
   __device__ __forceinline__ void amax(int32_t* p, int v) const { atomicMax(p, v); }
   __device__ __forceinline__ void aor(int32_t* p, int v) const { atomicOr(p, v); }

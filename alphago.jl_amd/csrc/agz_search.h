@@ -264,9 +264,16 @@ AGZ_FN int result_of(float score) { return score > 0.f ? 1 : score < 0.f ? -1 : 
 // ------------------------------------------------------------------ node pool
 
 template <class W>
-AGZ_FN int pool_alloc(W& w, const View& V, int g) {
+AGZ_FN int free_pending(W& w, const View& V, Scratch& S, int g, int budget);
+
+template <class W>
+AGZ_FN int pool_alloc(W& w, const View& V, Scratch& S, int g) {
   GameState& G = V.gs[g];
-  const int top = G.free_top;
+  int top = G.free_top;
+  if (top <= 0 && G.garbage > 0) {      // nothing free but releases pending: do them now
+    free_pending(w, V, S, g, V.cap);
+    top = G.free_top;
+  }
   if (top <= 0) {
     w.count(&V.counters[CT_POOL_EXHAUSTED], 1);
     if (w.leader()) G.err = AGZ_POOL_EXHAUSTED;
@@ -293,50 +300,54 @@ AGZ_FN void pool_free(W& w, const View& V, int g, int node) {
   w.sync();
 }
 
-// Free `start` and everything below it except the subtree rooted at `keep` (keep < 0: none).
-// Iterative: the work stack lives in the unused tail of the game's free list.
+// Deferred release of discarded subtrees.  play_move! drops the siblings of the chosen child
+// (`root.parent.children = Dict()`, mcts_play.jl:48); walking them at once put a serial walk over
+// thousands of nodes on the critical path of the ~2 % of games that move in a given step (k_pre took
+// as long as its slowest wave: 2.9 ms).  Instead the detached old root is pushed on a per-game
+// garbage stack -- it lives in the unused tail of the slot's free list and grows downward, while free
+// entries grow upward; they cannot collide because every stacked node is an allocated node and
+// #allocated + #free == cap -- and every k_pre releases at most `budget` nodes of it, children pushed
+// in ascending action order (a deterministic order: node ids never depend on timing).
 template <class W>
-AGZ_FN void free_subtree(W& w, const View& V, Scratch& S, int g, int start, int keep) {
+AGZ_FN int free_pending(W& w, const View& V, Scratch& S, int g, int budget) {
   GameState& G = V.gs[g];
-  // stack grows downward from the end of the freelist array; free entries grow upward.  They
-  // cannot collide: every stacked node is an allocated node, and #allocated + #free == cap.
   int32_t* fl = V.freelist + (long)g * V.cap;
-  int sp = V.cap;   // exclusive top of the downward stack
-  if (w.leader()) fl[--sp] = start; else --sp;
+  int sp = V.cap - G.garbage;
+  int done = 0;
   w.sync();
-  while (sp < V.cap) {
+  while (sp < V.cap && done < budget) {
     const int node = fl[sp];
     ++sp;
-    w.sync();
     const long ni = node_index(V, g, node);
     const bool expanded = V.meta[ni].flags & NF_EXPANDED;
-    // push children (ascending action order => deterministic free order)
-    if (expanded) {
-      for (int base = 0; base < V.A; base += kWave) {
-        int cnt = 0;
-        // compact the children of this 64-wide slice through the flag/label scratch
-        w.for_each(kWave, [&](int l) {
-          const int a = base + l;
-          int c = -1;
-          if (a < V.A) c = V.child[ni * V.AP + a];
-          if (c == keep) c = -1;
-          S.label[l] = c;
-        });
-        w.sync();
-        for (int l = 0; l < kWave; ++l) {
-          const int c = S.label[l];
-          if (c >= 0) { if (w.leader()) fl[sp - 1 - cnt] = c; ++cnt; }
-        }
-        sp -= cnt;
-        w.sync();
-      }
-    }
-    // release the node itself
+    w.sync();
+    if (expanded) sp = w.push_desc(V.A, [&](int a) { return V.child[ni * V.AP + a]; }, fl, sp);
     const int top = G.free_top;
     w.sync();
     if (w.leader()) { fl[top] = node; G.free_top = top + 1; G.nodes_used -= 1; V.meta[ni].flags = 0; }
     w.sync();
+    ++done;
   }
+  if (w.leader()) G.garbage = V.cap - sp;
+  w.sync();
+  return done;
+}
+
+// nodes released per step and game: a move creates <= R+7 nodes over ~R/8 steps, i.e. ~8 per step
+// in steady state; 32 keeps up with 4x headroom and costs ~30 us of a wave per step
+constexpr int kFreeBudget = 32;
+
+// detach `keep` from `start` and hand `start` (with everything else below it) to the garbage stack
+template <class W>
+AGZ_FN void discard_except(W& w, const View& V, int g, int start, int keep_action) {
+  GameState& G = V.gs[g];
+  w.sync();
+  if (w.leader()) {
+    if (keep_action >= 0) V.child[node_index(V, g, start) * V.AP + keep_action] = -1;
+    V.freelist[(long)g * V.cap + V.cap - G.garbage - 1] = start;
+    G.garbage = G.garbage + 1;
+  }
+  w.sync();
 }
 
 // ------------------------------------------------------------------ node creation
@@ -372,7 +383,7 @@ AGZ_FN int node_create_child(W& w, const View& V, Scratch& S, int g, int parent,
   const NodeMeta pm = V.meta[pi];
   const int P = V.P, N = V.N;
   if (a < 0 || a >= V.A || !legal_bit(V, pi, a)) return -2;
-  const int id = pool_alloc(w, V, g);
+  const int id = pool_alloc(w, V, S, g);
   if (id < 0) return -1;
   NodeMeta m;
   m.parent = parent;
@@ -687,7 +698,7 @@ AGZ_FN void reroot(W& w, const View& V, Scratch& S, int g, int a, int child) {
   const long oi = node_index(V, g, old_root);
   const float cn = V.childN[oi * V.AP + a], cw = V.childW[oi * V.AP + a];
   push_history(w, V, g, oi);
-  free_subtree(w, V, S, g, old_root, child);
+  discard_except(w, V, g, old_root, a);
   if (w.leader()) {
     G.rootN = cn;
     G.rootW = cw;
@@ -712,12 +723,12 @@ AGZ_FN void game_start(W& w, const View& V, Scratch& S, int g, uint64_t game_id)
     G.resign_threshold = G.resign_disabled ? -1.0 : V.resign_threshold;
     G.rootN = 0.f; G.rootW = 0.f; G.target = 0.f; G.komi = V.komi;
     G.sel = 0; G.move_count = 0; G.nqs = 0; G.hist_len = 0;
-    G.free_top = V.cap; G.nleaves = 0; G.err = 0; G.result = 0; G.was_resign = 0; G.nodes_used = 0;
+    G.free_top = V.cap; G.garbage = 0; G.nleaves = 0; G.err = 0; G.result = 0; G.was_resign = 0; G.nodes_used = 0;
     G.short_first = 0;
     G.phase = G_INIT;
   }
   w.sync();
-  const int id = pool_alloc(w, V, g);
+  const int id = pool_alloc(w, V, S, g);
   w.for_each(V.P, [&](int p) { S.sb[p] = 0; });
   w.sync();
   NodeMeta m;
@@ -1026,6 +1037,7 @@ AGZ_FN void arena_move_phase(W& w, const View& V, Scratch& S, int g) {
 template <class W>
 AGZ_FN void game_pre(W& w, const View& V, Scratch& S, int g) {
   GameState& G = V.gs[g];
+  if (G.garbage > 0 && G.phase != G_MANUAL) free_pending(w, V, S, g, kFreeBudget);
   if (V.arena && G.phase != G_MANUAL) { arena_pre(w, V, S, g); return; }
   if (G.phase == G_MANUAL || G.phase == G_RETIRED) {
     if (w.leader() && G.phase == G_RETIRED) G.nleaves = 0;
@@ -1211,14 +1223,14 @@ AGZ_FN void tree_op(W& w, const View& V, Scratch& S, const TreeArgs& T) {
       if (w.leader()) {
         G.rootN = 0.f; G.rootW = 0.f; G.target = 0.f; G.komi = T.info.komi;
         G.sel = 0; G.move_count = 0; G.nqs = 0; G.hist_len = T.info.history_len;
-        G.free_top = V.cap; G.nleaves = 0; G.err = 0; G.result = 0; G.was_resign = 0; G.nodes_used = 0;
+        G.free_top = V.cap; G.garbage = 0; G.nleaves = 0; G.err = 0; G.result = 0; G.was_resign = 0; G.nodes_used = 0;
         G.phase = G_MANUAL;
         G.resign_threshold = V.resign_threshold; G.resign_disabled = 0;
       }
       w.sync();
       for (int h = 0; h < T.info.history_len && h < 7; ++h)
         w.for_each(V.P, [&](int p) { V.hist[((long)g * 7 + h) * V.PP + p] = T.history[(long)h * V.P + p]; });
-      const int id = pool_alloc(w, V, g);
+      const int id = pool_alloc(w, V, S, g);
       w.for_each(V.P, [&](int p) { S.sb[p] = T.board[p]; });
       w.sync();
       NodeMeta m;
@@ -1277,6 +1289,7 @@ AGZ_FN void tree_op(W& w, const View& V, Scratch& S, const TreeArgs& T) {
       }
       w.sync();
       reroot(w, V, S, g, T.a, c);
+      free_pending(w, V, S, g, V.cap);      // single-tree API: release the dropped siblings right away
       if (w.leader()) { if (!V.two_player) G.move_count = k + 1; G.nqs = G.nqs + 1; }
       w.sync();
       r0 = 1;

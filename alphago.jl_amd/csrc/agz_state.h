@@ -60,6 +60,8 @@ struct GameState {
   int32_t nodes_used;
   int32_t short_first;       // bench stagger: the first search of this game has a shortened budget
   int32_t arena_k;           // arena: games this slot has finished (= local index of the current one)
+  int32_t garbage;           // nodes on the deferred-free stack (tail of the slot's free list)
+  int32_t pad;
 };
 
 enum Counter : int {

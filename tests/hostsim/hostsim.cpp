@@ -28,6 +28,14 @@ struct SimWave {
   float reduce_sum_f(float v) const { return v; }
   float reduce_max_f(float v) const { return v; }
   bool any(bool v) const { return v; }
+  template <class F>
+  int push_desc(int n, F get, int32_t* base, int sp) const {
+    for (int i = 0; i < n; ++i) {
+      const int c = get(i);
+      if (c >= 0) base[--sp] = c;
+    }
+    return sp;
+  }
   void amin(int32_t* p, int v) const { if (v < *p) *p = v; }
   void amax(int32_t* p, int v) const { if (v > *p) *p = v; }
   void aor(int32_t* p, int v) const { *p |= v; }

@@ -70,7 +70,7 @@ class GameState(C.Structure):
                 ("hist_len", C.c_int32), ("free_top", C.c_int32), ("nleaves", C.c_int32),
                 ("leaf_base", C.c_int32), ("resign_disabled", C.c_int32), ("err", C.c_int32),
                 ("result", C.c_int32), ("was_resign", C.c_int32), ("nodes_used", C.c_int32),
-                ("short_first", C.c_int32), ("pad", C.c_int32)]
+                ("short_first", C.c_int32), ("arena_k", C.c_int32), ("garbage", C.c_int32), ("pad", C.c_int32)]
 
 
 class TreeArgs(C.Structure):
