@@ -68,11 +68,32 @@ class NodeInfo(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (+ HSA runtime, comgr).  If libagz pulls
+    in /opt/rocm's copy first and torch is imported later in the same process, torch finds a
+    half-foreign runtime and reports "No HIP GPUs are available"; the other order works (libagz binds
+    to the runtime torch loaded).  So when torch is installed but not yet imported, load ITS
+    libamdhip64 first -- by path, without importing torch (that costs seconds to minutes).
+    AGZ_SYSTEM_HIP=1 keeps the system runtime (torch.cuda is then unusable in this process)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("AGZ_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+        if path and os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """dlopen libagz.so and declare every prototype of include/agz.h"""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

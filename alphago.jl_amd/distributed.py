@@ -54,17 +54,20 @@ def unpack_records(buf, A):
     return out
 
 
-def allgather_packed(packed, group=None, device=None):
-    """all-gather one uint8 buffer per rank; returns the concatenation in rank order (numpy uint8)"""
+def allgather_packed(packed, group=None, device=None, force_collective=False):
+    """all-gather one uint8 buffer per rank; returns the concatenation in rank order (numpy uint8).
+    `packed` is a numpy array or a torch tensor (a CUDA tensor from Engine.records_packed_device()
+    goes into the collective as it is -- device to device over RCCL/xGMI)."""
     import torch
     import torch.distributed as dist
 
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return np.ascontiguousarray(packed, np.uint8)
+    is_tensor = isinstance(packed, torch.Tensor)
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
+        return packed.cpu().numpy() if is_tensor else np.ascontiguousarray(packed, np.uint8)
     world = dist.get_world_size(group)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    mine = torch.from_numpy(np.ascontiguousarray(packed, np.uint8)).to(device)
+    mine = packed.to(device) if is_tensor else torch.from_numpy(np.ascontiguousarray(packed, np.uint8)).to(device)
     size = torch.tensor([mine.numel()], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size, group=group)
@@ -77,8 +80,15 @@ def allgather_packed(packed, group=None, device=None):
     return np.concatenate([p[:s].cpu().numpy() for p, s in zip(parts, sizes)]) if sum(sizes) else np.zeros(0, np.uint8)
 
 
-def allgather_records(engine_or_records, A, group=None):
-    """engine (has .records_packed()) or a list of record dicts -> every rank's records, by game id"""
-    packed = engine_or_records.records_packed() if hasattr(engine_or_records, "records_packed") else pack_records(engine_or_records, A)
-    recs = unpack_records(allgather_packed(packed, group), A)
+def allgather_records(engine_or_records, A, group=None, force_collective=False):
+    """engine or a list of record dicts -> every rank's records, by game id.  With the nccl (RCCL)
+    backend an engine's records go from its HBM arena into the collective without touching the host."""
+    import torch.distributed as dist
+
+    if hasattr(engine_or_records, "records_packed"):
+        on_device = dist.is_initialized() and dist.get_backend(group) == "nccl" and hasattr(engine_or_records, "records_packed_device")
+        packed = engine_or_records.records_packed_device() if on_device else engine_or_records.records_packed()
+    else:
+        packed = pack_records(engine_or_records, A)
+    recs = unpack_records(allgather_packed(packed, group, force_collective=force_collective), A)
     return sorted(recs, key=lambda r: r["game_id"])

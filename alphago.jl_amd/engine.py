@@ -274,6 +274,16 @@ class Engine:
         self._ck(self.L.agz_records_export_packed(self.h, buf.ctypes.data_as(C.c_void_p), n.value, 0))
         return buf[: n.value]
 
+    def records_packed_device(self):
+        """the same packed records written straight into a CUDA uint8 tensor (no host staging):
+        the send buffer of the RCCL replay all-gather"""
+        import torch
+        n = C.c_int64()
+        self._ck(self.L.agz_records_packed_size(self.h, C.byref(n)))
+        buf = torch.empty(max(n.value, 1), dtype=torch.uint8, device=torch.device("cuda", self.cfg.device))
+        self._ck(self.L.agz_records_export_packed(self.h, C.c_void_p(buf.data_ptr()), n.value, 1))
+        return buf[: n.value]
+
     def records_clear(self):
         self._ck(self.L.agz_records_clear(self.h))
 

@@ -134,3 +134,38 @@ def test_neuralnet_and_selfplay_api():  # src/neural_net.jl:57-73, src/selfplay.
         assert len(positions) == len(pis) == len(results) == len(r.moves) >= 1
         assert all(z == r.result for z in results)
         assert positions[0].n == 0 and positions[-1].n == len(r.moves) - 1
+
+
+def test_replay_allgather_over_rccl_from_device_records():
+    """SURVEY.md 8e exchange step on the real backend: finished games leave the engine's HBM arena
+    as one packed CUDA buffer and go through torch.distributed's nccl (= RCCL) all-gather.  One GPU
+    here, so the group has one rank; the collective path is forced."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from alphago_jl_amd.distributed import allgather_records, unpack_records
+
+    eng = ag.Engine(board_size=5, tower_height=1, games=4, num_readouts=16, seed=7, record_capacity_games=16)
+    eng.init_synthetic(0)
+    eng.start(6)
+    while eng.records_count() < 6:
+        eng.step(8)
+    want = eng.records()
+    dev = eng.records_packed_device()
+    assert dev.is_cuda and (dev.cpu().numpy() == eng.records_packed()).all()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = allgather_records(eng, eng.A, force_collective=True)
+    finally:
+        dist.destroy_process_group()
+    assert [r["game_id"] for r in got] == sorted(r["game_id"] for r in want)
+    by_id = {r["game_id"]: r for r in want}
+    for r in got:
+        w = by_id[r["game_id"]]
+        assert (r["moves"] == w["moves"]).all() and r["result"] == w["result"]
+        assert (np.nan_to_num(r["pis"]) == np.nan_to_num(w["pis"])).all()
+    eng.close()

@@ -126,3 +126,33 @@ def test_properties_at_scale():
         assert (r1["moves"] == r2["moves"]).all() and bits_equal(r1["pis"], r2["pis"])
     eng.close()
     eng2.close()
+
+
+def test_full_size_config_invariants():
+    """BASELINE.json configs[1] at full size (GoEnv(9), tower 10, 400 readouts, 1024 concurrent games,
+    batches of up to 8192 leaves) for 60 steps: properties that need no oracle."""
+    N, A, G, R = 9, 82, 1024, 400
+    eng = ag.Engine(board_size=N, tower_height=10, games=G, num_readouts=R, seed=11, stagger_moves=40)
+    eng.init_synthetic(0)
+    eng.start(0)
+    eng.step(60)
+    st = eng.stats()
+    assert st["pool_exhausted"] == 0 and st["steps"] == 60
+    assert st["evals"] <= 60 * 8 * G and st["evals"] >= 0.9 * 59 * 8 * G           # the batch stays full
+    assert st["root_visits"] >= st["evals"] - G                                     # every collected leaf is a visit
+    assert st["positions"] > 0 and st["games_started"] >= G     # (a game's shortened first move is not counted)
+    rng = np.random.RandomState(0)
+    for g in rng.choice(G, 24, replace=False):
+        g = int(g)
+        root = eng.tree_root(g)
+        info = eng.node_info(g, root)
+        assert eng.pending_vlosses(g) == 0                                           # mcts_play.jl:92: all reverted
+        cn = eng.node_floats(g, root, 0)
+        assert (cn >= 0).all() and (cn == np.round(cn)).all()
+        if info.is_expanded:
+            assert info.N == 1 + cn.sum() or info.N == cn.sum()                      # the root's own first visit
+            legal = eng.go_legal(eng.node_board(g, root)[None], [info.pos.to_play], [info.pos.ko])[0]
+            assert not (cn[legal == 0] > 0).any()                                    # test_mcts.jl:146-167 at scale
+            prior = eng.node_floats(g, root, 2)
+            assert abs(prior.sum() - 1.0) < 1e-3                                     # 0.75 p + 0.25 dirichlet
+    eng.close()
