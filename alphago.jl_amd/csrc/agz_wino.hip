@@ -210,9 +210,23 @@ __device__ __forceinline__ void wino_gemm_body(float (*lds)[STAGE], const float*
     const float* a = asrc + (long)st * A_STAGE;
     const float* b = bsrc + (long)st * B_STAGE;
     for (int c = wave; c < 52; c += 12) {
+      if ((DBG == 7 && c >= 26) || (DBG == 8 && c < 26)) continue;     // timing: only the V / only the U stream
       const float* g = c < 26 ? a + c * 256 : b + (c - 26) * 256;
       glds16(g + lane * 4, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
     }
+  };
+
+  // the j-th chunk of this wave (c = wave + 12 j).  The five DMA instructions of a stage are spread
+  // between the MFMAs of the K loop: issued in one block at the top of a stage -- by all twelve
+  // waves at once, straight after the barrier -- their ~90 scalar/VALU/VMEM instructions per wave
+  // kept every wave of a SIMD off the MFMA pipe at the same time (measured: +0.6 ms per layer even
+  // with the loads never waited for and the MFMAs fed from constants).
+  auto dma = [&](int st, int buf, int j) {
+    const int c = wave + 12 * j;
+    if (c >= 52) return;
+    if ((DBG == 7 && c >= 26) || (DBG == 8 && c < 26)) return;       // timing: only the V / only the U stream
+    const float* g = c < 26 ? asrc + (long)st * A_STAGE + c * 256 : bsrc + (long)st * B_STAGE + (c - 26) * 256;
+    glds16(g + lane * 4, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
   };
 
   f32x16 acc[NX];
@@ -235,32 +249,68 @@ __device__ __forceinline__ void wino_gemm_body(float (*lds)[STAGE], const float*
   else if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __syncthreads();
+  // Software-pipelined across the barrier.  Reading a stage's operands only after the barrier that
+  // publishes it left the LDS latency -- ~600 cycles under DMA write traffic -- exposed once per
+  // 3200-cycle stage (0.6 ms of 2.6 per layer).  So the LAST planes of every stage (NH of them) are
+  // "held back": their operands are read before the barrier, their MFMAs are issued after it, right
+  // behind the first reads of the next stage, whose latency they cover.  The 8-plane groups hold two
+  // planes (8 VGPRs); the 9-plane group has no register to spare (144 accumulators) and holds none --
+  // its reads hide behind the held MFMAs of the two other waves of its SIMD.
+  constexpr int NH = PG == 0 ? 0 : 2, NS = NX - NH;
+  float2 aH[NH + 1], bH[NH + 1];
+  auto load = [&](const float* L, int k, float2& a, float2& b) {
+    const int xi = X0 + k;
+    const int lp = 2 * (xi & 1) + hi;
+    a = *reinterpret_cast<const float2*>(L + abase + (xi >> 1) * WT * 8 + 2 * ((lp + arot) & 3));
+    b = *reinterpret_cast<const float2*>(L + bbase + (xi >> 1) * WC * 8 + 2 * ((lp + brot) & 3));
+    if (DBG == 4 || DBG == 5 || DBG == 9) { a = make_float2(1.f, 1.f); b = make_float2(2.f, (float)lane); }   // timing: no LDS reads
+  };
+  auto mma = [&](int k, const float2& a, const float2& b) {
+    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[k], 0, 0, 0);
+    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
+  };
   int buf = 0;
   for (int st = 0; st < WNS; ++st) {
     const int nbuf = buf == 0 ? 2 : buf - 1;            // (st + 2) % 3
     const bool more = st + 2 < WNS && DBG != 1 && DBG != 3 && DBG != 4 && DBG != 5;
-    if (more) issue(st + 2, nbuf);
     const float* L = lds[buf];
-    if (DBG != 2) {
+    if (DBG == 2) {
+      if (more) issue(st + 2, nbuf);
+    } else {
+      // operands are read one plane ahead (two register pairs, alternating); the DMA instruction of
+      // a slot sits between that read and the MFMAs it will feed
+      float2 ra[2], rb[2];
+      load(L, 0, ra[0], rb[0]);
+      if (st > 0) {
 #pragma unroll
-      for (int k = 0; k < NX; ++k) {
-        constexpr int dummy = 0;
-        const int xi = X0 + k;
-        const int lp = 2 * (xi & 1) + hi;
-        float2 a = *reinterpret_cast<const float2*>(L + abase + (xi >> 1) * WT * 8 + 2 * ((lp + arot) & 3));
-        float2 b = *reinterpret_cast<const float2*>(L + bbase + (xi >> 1) * WC * 8 + 2 * ((lp + brot) & 3));
-        if (DBG == 4 || DBG == 5) { a = make_float2((float)st, 1.f); b = make_float2(2.f, (float)lane); }   // timing: no LDS reads
-        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[k], 0, 0, 0);
-        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
-        (void)dummy;
+        for (int k = 0; k < NH; ++k) mma(NS + k, aH[k], bH[k]);     // the previous stage's held planes
       }
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        if (k + 1 < NS) load(L, k + 1, ra[(k + 1) & 1], rb[(k + 1) & 1]);
+        if (k < 5) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) dma(st + 2, nbuf, k);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mma(k, ra[k & 1], rb[k & 1]);
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k) load(L, NS + k, aH[k], bH[k]);
     }
-    // this wave's share of stage st+1 has landed (stage st+2 may still be in flight) ...
-    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // this wave's share of stage st+1 has landed (stage st+2 may still be in flight) ...  (hipcc puts
+    // an s_waitcnt lgkmcnt(0) in front of the barrier itself: every LDS read of stage st has
+    // returned before any wave can overwrite that buffer with the DMA of stage st+3)
+    if (DBG == 6 || DBG == 7 || DBG == 8 || DBG == 9) { if (st == WNS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // timing: never wait for the DMA
+    else if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (DBG != 3) __syncthreads();                      // ... and so has everybody else's
     buf = buf == 2 ? 0 : buf + 1;
+  }
+  if (DBG != 2) {
+#pragma unroll
+    for (int k = 0; k < NH; ++k) mma(NS + k, aH[k], bH[k]);
   }
 
   // epilogue.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e&3) + 8*(e>>2) + 4*(lane>>5),
@@ -423,7 +473,7 @@ void launch_wino_conv(const float* x, float* vimg, const float* uimg, const floa
   const int blocks = (int)(((long)bcap * T * T + WT - 1) / WT);
   hipLaunchKernelGGL((k_wino_in<32, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
   static const int dbg = getenv("AGZ_WINO_DEBUG") ? atoi(getenv("AGZ_WINO_DEBUG")) : 0;   // timing experiments only
-  auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : dbg == 3 ? k_wino_gemm<3> : dbg == 4 ? k_wino_gemm<4> : dbg == 5 ? k_wino_gemm<5> : k_wino_gemm<0>;
+  auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : dbg == 3 ? k_wino_gemm<3> : dbg == 4 ? k_wino_gemm<4> : dbg == 5 ? k_wino_gemm<5> : dbg == 6 ? k_wino_gemm<6> : dbg == 7 ? k_wino_gemm<7> : dbg == 8 ? k_wino_gemm<8> : dbg == 9 ? k_wino_gemm<9> : k_wino_gemm<0>;
   const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm
   hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(768), 0, s, (const float*)vimg, uimg, scale, shift,
                      res, y, d_count, N, T, relu);
