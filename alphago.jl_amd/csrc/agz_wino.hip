@@ -279,21 +279,23 @@ __device__ __forceinline__ void wino_gemm_body(float (*lds)[STAGE], const float*
     } else {
       // operands are read one plane ahead (two register pairs, alternating); the DMA instruction of
       // a slot sits between that read and the MFMAs it will feed
-      float2 ra[2], rb[2];
-      load(L, 0, ra[0], rb[0]);
+      constexpr int LA = 1;   // planes read ahead of the MFMAs (register ring of LA + 1; 2 was measured slower)
+      float2 ra[LA + 1], rb[LA + 1];
+#pragma unroll
+      for (int k = 0; k < LA; ++k) load(L, k, ra[k], rb[k]);
       if (st > 0) {
 #pragma unroll
         for (int k = 0; k < NH; ++k) mma(NS + k, aH[k], bH[k]);     // the previous stage's held planes
       }
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        if (k + 1 < NS) load(L, k + 1, ra[(k + 1) & 1], rb[(k + 1) & 1]);
+        if (k + LA < NS) load(L, k + LA, ra[(k + LA) % (LA + 1)], rb[(k + LA) % (LA + 1)]);
         if (k < 5) {
           __builtin_amdgcn_sched_barrier(0);
           if (more) dma(st + 2, nbuf, k);
           __builtin_amdgcn_sched_barrier(0);
         }
-        mma(k, ra[k & 1], rb[k & 1]);
+        mma(k, ra[k % (LA + 1)], rb[k % (LA + 1)]);
       }
 #pragma unroll
       for (int k = 0; k < NH; ++k) load(L, NS + k, aH[k], bH[k]);
