@@ -6,12 +6,15 @@ tools/nn_micro.py --batches B --algos 1.
   rocprofv3 --pmc WRITE_SIZE ...                                  -d gpurun_out/pmc_WRITE_SIZE ...
   python tools/pmc_traffic.py 8192 9 gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > profiles/pmc_traffic.json
 
-Units and calibration (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your
-own access pattern"): the counters are KiB per dispatch.  k_wino_gemm's WRITE_SIZE equals the
-algorithmic output bytes exactly (B*N^2*256*4 B), k_wino_in's FETCH_SIZE is 1.085x its algorithmic
-input (8 B/lane loads) -- so both are taken at face value (x1.0); the halving the guide reports for
-16 B/lane streaming reads is NOT observed for the gemm's global_load_lds_dwordx4 stream here
-(halved, V alone would read 0.94 GB; the counter says 2.36 GB against 1.89 GB V + 0.34 GB residual).
+Units and calibration (MI355X_MICROARCH.md, HBM section: "FETCH_SIZE reports exactly 1/2 of the bytes
+of a wide coalesced streaming read ... double it", "other access widths and WRITE_SIZE are
+uncalibrated: calibrate on a known byte count in your own access pattern").  The counters are KiB per
+dispatch.  Known byte counts here: k_wino_gemm writes exactly B*N^2*256*4 B and WRITE_SIZE reports
+that number (x1.0); k_wino_in must read its B*N^2*256*4 B input at least once.  Its FETCH_SIZE was
+1.085x that with the first version of the kernel and is 0.53x with the LDS-staged one -- the same
+bytes now arrive as 128-B requests tallied at 64 B -- so a kernel whose FETCH_SIZE is below its
+compulsory input is corrected x2, as the guide prescribes; both raw and corrected values are kept.
+The gemm's global_load_lds_dwordx4 stream reads 1.12x (V + residual + the L2 misses of U): x1.0.
 """
 import collections
 import csv
@@ -32,9 +35,13 @@ for k, cs in agg.items():
     if "wino" not in k:
         continue
     per_kernel[k] = {c: 1024.0 * sum(v) / len(v) for c, v in cs.items()}
-    total += sum(per_kernel[k].values())
+    if "wino_in" in k and per_kernel[k].get("FETCH_SIZE", 0) < rows * 1024.0:
+        per_kernel[k]["FETCH_SIZE_raw"] = per_kernel[k]["FETCH_SIZE"]
+        per_kernel[k]["FETCH_SIZE"] *= 2.0
+        per_kernel[k]["FETCH_SIZE_correction"] = "x2: below the compulsory input, 128-B requests tallied at 64 B"
+    total += sum(v for c, v in per_kernel[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE"))
 print(json.dumps({
-    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/nn_micro.py --batches {B}, gfx950; KiB counters x1.0 (calibrated on known byte counts, see tools/pmc_traffic.py)",
+    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/nn_micro.py --batches {B}, gfx950; KiB counters, per-kernel calibration on known byte counts (see tools/pmc_traffic.py)",
     "rows_per_launch": rows, "bytes_per_launch": total, "bytes_per_row": total / rows,
     "algorithmic_bytes_per_row": 2.5 * 256 * 4,
     "per_kernel_bytes_per_launch": per_kernel,
