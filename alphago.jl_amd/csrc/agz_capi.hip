@@ -148,6 +148,13 @@ agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_
 agz_status agz_net_set_winograd(agz_engine* e, int32_t on) {
   return guard(e, [&](agz::Engine& E) { E.net().set_winograd(on != 0); });
 }
+agz_status agz_net_set_precision(agz_engine* e, int32_t precision) {
+  return guard(e, [&](agz::Engine& E) {
+    AGZ_REQUIRE(precision == AGZ_PRECISION_F32 || precision == AGZ_PRECISION_F16, AGZ_BAD_ARGUMENT,
+                "precision %d (0 = f32, 1 = f16 tower)", precision);
+    E.net().set_precision(precision);
+  });
+}
 agz_status agz_profile_conv_enable(agz_engine* e, int32_t on) {
   return guard(e, [&](agz::Engine& E) { E.net().profile_enable(on != 0); });
 }

@@ -48,6 +48,9 @@ class Net {
   // tower convolution algorithm: Winograd F(3x3,3x3) (default) or the direct implicit GEMM
   void set_winograd(bool on) { winograd_ = on; }
   bool winograd() const { return winograd_; }
+  // tower arithmetic: 0 = exact f32 (default), 1 = fp16 operands / f32 accumulate (agz_conv16.hip)
+  void set_precision(int p) { precision_ = p; dirty_ = dirty_ || p == 1; }
+  int precision() const { return precision_; }
 
   // HIP-event timing of every tower-conv launch inside forward() (bench.py roofline leg)
   void profile_enable(bool on);
@@ -80,6 +83,10 @@ class Net {
   DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
   bool winograd_ = true;
   DevBuf<float> d_uwino_, d_vimg_;        // transformed weights (stage images) / transformed activations
+  int precision_ = 0;
+  bool packed16_ = false;
+  DevBuf<uint16_t> d_wh16_;               // fp16 tower weights [layer][chunk][tap][cout][32]
+  DevBuf<uint16_t> d_ha_, d_hb_, d_ht_;   // fp16 tower activations [rows][256]
   // profiling
   bool prof_on_ = false;
   std::vector<hipEvent_t> prof_ev_;
@@ -95,6 +102,13 @@ size_t wino_weight_floats();
 size_t wino_v_floats(int bcap, int T);
 void launch_wino_conv(const float* x, float* vimg, const float* uimg, const float* scale, const float* shift,
                       const float* res, float* y, const int* d_count, int bcap, int N, int relu, hipStream_t s);
+
+// fp16-operand tower convolution (agz_conv16.hip); x / res / y are float* or half* as flagged
+void conv16_pack_weights(const ConvHost& c, uint16_t* out);
+size_t conv16_weight_halves();
+void launch_conv16(const void* x, int in_f32, const uint16_t* wh, const float* scale, const float* shift,
+                   const void* res, int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu,
+                   hipStream_t s);
 
 // feature extraction entry points (features.jl:3-26) from the reference's own position format
 void launch_features_from_deltas(const int8_t* d_boards, const int8_t* d_deltas, const int32_t* d_ndeltas,

@@ -472,7 +472,18 @@ static void bn_affine(const ConvHost& c, float* scale, float* shift) {
 }
 
 void Net::pack() {
+  if (!dirty_ && (precision_ != 1 || packed16_)) return;
+  if (precision_ == 1 && tower_ > 0 && (dirty_ || !packed16_)) {
+    const size_t per = conv16_weight_halves();
+    std::vector<uint16_t> w(per * 2 * tower_);
+    for (int l = 0; l < 2 * tower_; ++l) conv16_pack_weights(tconv_[l], w.data() + per * l);
+    d_wh16_.ensure(w.size());
+    AGZ_HIP(hipMemcpyAsync(d_wh16_.p, w.data(), w.size() * sizeof(uint16_t), hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
+    packed16_ = true;
+  }
   if (!dirty_) return;
+  if (precision_ != 1) packed16_ = false;
   const int L = 1 + 2 * tower_;
   std::vector<float> scale((size_t)L * kC), shift((size_t)L * kC);
   {
@@ -526,6 +537,12 @@ void Net::pack() {
 }
 
 void Net::reserve(int bcap) {
+  if (precision_ == 1 && tower_ > 0 && d_ha_.n < (size_t)std::max(bcap, bcap_) * P_ * kC) {
+    const size_t n = (size_t)std::max(bcap, bcap_) * P_ * kC;
+    d_ha_.alloc(n);
+    d_hb_.alloc(n);
+    d_ht_.alloc(n);
+  }
   if (bcap <= bcap_) return;
   const size_t rows = (size_t)bcap * P_;
   d_a_.alloc(rows * kC);
@@ -549,6 +566,33 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
   hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad>), dim3(grid), dim3(256), 0, stream_, d_x32, d_wstem_.p,
                      d_scale_.p, d_shift_.p, (const float*)nullptr, a, d_count, N_, 1);
   const size_t per = (size_t)kC * 9 * kC;
+  if (precision_ == 1 && tower_ > 0) {
+    // fp16 tower: the first conv reads the f32 stem output (rounded on load), the last one writes
+    // f32 for the heads; everything in between lives in half buffers
+    const size_t hper = conv16_weight_halves();
+    const void* cur = a;          // block input (f32 for block 0, half afterwards)
+    int cur_f32 = 1;
+    uint16_t *ha = d_ha_.p, *hb = d_hb_.p;
+    for (int blk = 0; blk < tower_; ++blk) {
+      const int l1 = 2 * blk, l2 = 2 * blk + 1;
+      const bool last = blk + 1 == tower_;
+      const bool p1 = prof_on_ && prof_n_ < kProfMax;
+      if (p1) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+      launch_conv16(cur, cur_f32, d_wh16_.p + hper * l1, d_scale_.p + (size_t)(l1 + 1) * kC,
+                    d_shift_.p + (size_t)(l1 + 1) * kC, nullptr, 0, d_ht_.p, 0, d_count, bcap, N_, 1, stream_);
+      if (p1) { (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_); prof_fwd_of_[prof_n_++] = prof_fwd_; }
+      const bool p2 = prof_on_ && prof_n_ < kProfMax;
+      if (p2) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+      void* out = last ? (void*)b : (void*)ha;
+      launch_conv16(d_ht_.p, 0, d_wh16_.p + hper * l2, d_scale_.p + (size_t)(l2 + 1) * kC,
+                    d_shift_.p + (size_t)(l2 + 1) * kC, cur, cur_f32, out, last ? 1 : 0, d_count, bcap, N_, 1, stream_);
+      if (p2) { (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_); prof_fwd_of_[prof_n_++] = prof_fwd_; }
+      cur = ha;
+      cur_f32 = 0;
+      std::swap(ha, hb);
+    }
+    a = b;     // heads read the f32 output of the last block
+  } else
   for (int blk = 0; blk < tower_; ++blk) {
     const int l1 = 2 * blk, l2 = 2 * blk + 1;
     const bool p1 = prof_on_ && prof_n_ < kProfMax;
@@ -622,7 +666,10 @@ void Net::launch_tower_conv_once(const int* d_count, int bcap) {
   reserve(bcap);
   AGZ_REQUIRE(tower_ > 0, AGZ_BAD_ARGUMENT, "no tower conv in a tower_height=0 network");
   const int grid = conv_grid(bcap, P_);
-  if (winograd_)
+  if (precision_ == 1)
+    launch_conv16(d_ha_.p, 0, d_wh16_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, 0, d_ht_.p, 0, d_count, bcap, N_, 1,
+                  stream_);
+  else if (winograd_)
     launch_wino_conv(d_a_.p, d_vimg_.p, d_uwino_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, d_t_.p, d_count, bcap,
                      N_, 1, stream_);
   else

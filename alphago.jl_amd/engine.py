@@ -135,6 +135,11 @@ class Engine:
     def set_winograd(self, on=True):
         self._ck(self.L.agz_net_set_winograd(self.h, 1 if on else 0))
 
+    def set_precision(self, precision="f32"):
+        """tower arithmetic: "f32" (default, exact) or "f16" (fp16 operands, f32 accumulate)"""
+        code = {"f32": 0, "f16": 1, 0: 0, 1: 1}[precision]
+        self._ck(self.L.agz_net_set_precision(self.h, code))
+
     def profile_conv(self, on=True):
         self._ck(self.L.agz_profile_conv_enable(self.h, 1 if on else 0))
 

@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--stagger", type=int, default=60, help="random opening prefix (moves) so games are at mixed stages")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
+                    help="tower arithmetic: f32 (default, the BASELINE metric) or f16 = the fp16 MFMA path of BASELINE configs[4]")
     ap.add_argument("--single-device-test", action="store_true",
                     help="testing only: every rank uses cuda:0 and gloo, to exercise the multi-rank code path on a 1-GPU box")
     args = ap.parse_args()
@@ -158,6 +160,7 @@ def main():
                     seed=1, game_id_base=rank, game_id_stride=world, device=local_rank,
                     stagger_moves=args.stagger)
     eng.init_synthetic(0)
+    eng.set_precision(args.precision)
     eng.start(0)
 
     def barrier():
@@ -206,13 +209,15 @@ def main():
         value = d["positions"] / elapsed
         fpos = R * f_eval(N, tower)
         T = (N + 2) // 3
-        wino_ratio = 25.0 * T * T / (81.0 * N * N) * 9.0   # executed / algorithmic multiplies of F(3x3,3x3)
-        traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256))
+        f16 = args.precision == "f16"
+        wino_ratio = 1.0 if f16 else 25.0 * T * T / (81.0 * N * N) * 9.0   # executed / algorithmic multiplies of F(3x3,3x3)
+        peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
+        traffic, traffic_src = (None, None) if (f16 or N != 9) else pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256))
         out = {
-            "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)",
+            "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)" + (" [fp16 tower]" if f16 else ""),
             "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
             "config": {
                 "workload": f"GoEnv({N}), tower_height={tower}, {R} readouts, {args.games} concurrent games per GPU, "
                             f"8 leaves per game per step (batch <= {8 * args.games} positions)",
@@ -224,21 +229,22 @@ def main():
             "evals_per_position": d["evals"] / max(d["positions"], 1),
             "readout_positions_per_s": d["root_visits"] / R / elapsed,
             "games_finished": d["games_finished"],
-            "end_to_end_mfma_frac": value * fpos / (world * PEAK_F32_MFMA_TFLOPS * 1e12),
+            "end_to_end_mfma_frac": value * fpos / (world * peak * 1e12),
             "roofline": {
                 "bound": "mfma",
-                "kernel": "3x3 256->256 tower conv = k_wino_in + k_wino_gemm (Winograd F(3x3,3x3), v_mfma_f32_32x32x2_f32)",
+                "kernel": "3x3 256->256 tower conv = k_conv3x3_f16 (implicit GEMM, v_mfma_f32_32x32x16_f16)" if f16 else
+                          "3x3 256->256 tower conv = k_wino_in + k_wino_gemm (Winograd F(3x3,3x3), v_mfma_f32_32x32x2_f32)",
                 "note": "achieved = ALGORITHMIC flops of the direct convolution (2*rows*9*256*256 per launch) / launch time; "
                         "Winograd executes 3.24x fewer multiplies, all in f32, so frac may exceed 1",
                 "achieved": conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": (conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
+                "peak": peak, "unit": "TFLOP/s",
+                "frac": (conv_flop / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
                 "flop_per_launch_avg": conv_flop / max(conv_n, 1),
                 # what the MFMA pipe actually executes: 25 multiplies per 3x3 output tile and (cin, cout)
                 "executed_flop_per_launch_avg": conv_flop * wino_ratio / max(conv_n, 1),
-                "executed_frac": (conv_flop * wino_ratio / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
+                "executed_frac": (conv_flop * wino_ratio / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -132,6 +132,14 @@ agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_
 /* tower-convolution algorithm: 1 (default) = Winograd F(3x3,3x3) on the f32 MFMA, 0 = direct
  * implicit GEMM on the f32 MFMA.  Both are f32 end to end; they differ by rounding only. */
 agz_status agz_net_set_winograd(agz_engine* e, int32_t on);
+/* tower arithmetic of the network selected by agz_net_select.  AGZ_PRECISION_F32 (default): exact
+ * f32 end to end -- the parity target of BASELINE.json's metric.  AGZ_PRECISION_F16: the "fp16 MFMA
+ * path" of BASELINE.json configs[4]: tower activations and weights are rounded to IEEE half, products
+ * accumulate in f32 (v_mfma_f32_32x32x16_f16); stem, heads, BatchNorm affine and residual adds stay
+ * f32.  Mixed-precision inference: outputs agree with the f32 network to ~1e-3, not 1e-4. */
+#define AGZ_PRECISION_F32 0
+#define AGZ_PRECISION_F16 1
+agz_status agz_net_set_precision(agz_engine* e, int32_t precision);
 
 /* HIP-event timing of every 3x3 256->256 tower-conv launch issued by subsequent steps /
  * forwards (up to 4096 launches), on the engine's own stream.  read() synchronises and returns

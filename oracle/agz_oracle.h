@@ -214,7 +214,10 @@ int64_t or_net_param_count(const ONet* net, int layer, int kind);
 void or_net_init_synthetic(ONet* net, uint64_t seed);
 int or_net_get(const ONet* net, int layer, int kind, float* out, int64_t count);
 /* forward on feature tensors x (N*N*17 per position, WHCN); precision 32 or 64 */
+/* precision: 32 = float, 64 = double, 16 = the fp16-operand tower of agz_net_set_precision(F16)
+ * restated (tower weights / activations rounded to IEEE half where the GPU stores them, float64 sums) */
 void or_net_forward_feats(const ONet* net, const float* x, int B, float* pi, float* v, int precision);
+float or_quant_half(float f);                      /* float -> nearest half (ties to even) -> float */
 void or_net_forward_feats_f64(const ONet* net, const double* x, int B, double* pi, double* v);
 /* a or_net_fn over an ONet (ctx = ONet*), fp32 compute */
 void or_net_callable(void* ctx, const OPos* const* positions, int B, float* pi, float* v);

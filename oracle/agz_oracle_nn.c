@@ -36,6 +36,7 @@ typedef struct {
   float eps;
   float* wp;                 /* packed [tap][cin][cout], flip applied */
   float* wpn;                /* the same as 16-channel panels [cout/16][tap][cin][16] (cout % 16 == 0) */
+  float *wp16, *wpn16;       /* wp / wpn rounded to IEEE half (the fp16-operand mode, precision 16) */
   int dirty;
 } OConv;
 
@@ -59,6 +60,8 @@ static void conv_alloc(OConv* c, int k, int cin, int cout) {
   c->w = (float*)calloc(nw, sizeof(float));
   c->wp = (float*)calloc(nw, sizeof(float));
   c->wpn = (float*)calloc(nw, sizeof(float));
+  c->wp16 = (float*)calloc(nw, sizeof(float));
+  c->wpn16 = (float*)calloc(nw, sizeof(float));
   c->b = (float*)calloc((size_t)cout, sizeof(float));
   c->beta = (float*)calloc((size_t)cout, sizeof(float));
   c->gamma = (float*)calloc((size_t)cout, sizeof(float));
@@ -69,6 +72,7 @@ static void conv_alloc(OConv* c, int k, int cin, int cout) {
   c->dirty = 1;
 }
 static void conv_free(OConv* c) {
+  free(c->wp16); free(c->wpn16);
   free(c->w); free(c->wp); free(c->wpn); free(c->b); free(c->beta); free(c->gamma); free(c->mean); free(c->var);
 }
 static void dense_alloc(ODense* d, int in, int out) {
@@ -181,6 +185,27 @@ void or_net_init_synthetic(ONet* n, uint64_t seed) {
   glorot(n->pfc.w, (int64_t)n->pfc.in * n->pfc.out, n->pfc.in, n->pfc.out, seed, OR_L_POLICY_FC);
 }
 
+/* round a float to the nearest IEEE binary16 value (ties to even), returned as float: what a
+ * float -> half -> float round trip does on the GPU (v_cvt_f16_f32, __float2half_rn) */
+static float quant_h(float f) {
+  union { float f; uint32_t u; } v;
+  v.f = f;
+  uint32_t sign = v.u & 0x80000000u, a = v.u & 0x7fffffffu;
+  if (a >= 0x7f800000u) return f;                       /* inf / nan */
+  if (a >= 0x477ff000u) { v.u = sign | 0x7f800000u; return v.f; }   /* >= 65520 rounds to inf */
+  if (a < 0x38800000u) {                                /* below 2^-14: half subnormals, quantum 2^-24 */
+    float q = 5.9604644775390625e-08f;
+    float r = rintf(fabsf(f) / q) * q;                  /* rintf: round-half-even in the default mode */
+    return sign ? -r : r;
+  }
+  uint32_t lsb = (a >> 13) & 1u;
+  a += 0x0fffu + lsb;
+  a &= ~0x1fffu;
+  v.u = sign | a;
+  return v.f;
+}
+float or_quant_half(float f) { return quant_h(f); }
+
 /* [kw,kh,cin,cout] -> [tap=(da,db)][cin][cout] where the tap reads x[i+da, j+db].
  * True convolution: Flux index (a,b) (0-based) multiplies x[i + 1 - a, j + 1 - b] for k=3. */
 static void conv_pack(OConv* c) {
@@ -201,6 +226,10 @@ static void conv_pack(OConv* c) {
         for (int ci = 0; ci < cin; ++ci)
           memcpy(c->wpn + (((size_t)nb * k * k + tap) * cin + ci) * 16,
                  c->wp + ((size_t)tap * cin + ci) * cout + nb * 16, 16 * sizeof(float));
+  {
+    size_t nw = (size_t)k * k * cin * cout;
+    for (size_t i = 0; i < nw; ++i) { c->wp16[i] = quant_h(c->wp[i]); c->wpn16[i] = quant_h(c->wpn[i]); }
+  }
   c->dirty = 0;
 }
 
@@ -246,6 +275,18 @@ void or_net_forward_feats(const ONet* n, const float* x, int B, float* pi, float
     double* vd = (double*)malloc(sizeof(double) * (size_t)B);
     for (size_t i = 0; i < nx; ++i) xd[i] = x[i];
     forward_f64(n, xd, B, pid, vd);
+    for (size_t i = 0; i < (size_t)B * n->A; ++i) pi[i] = (float)pid[i];
+    for (int b = 0; b < B; ++b) v[b] = (float)vd[b];
+    free(xd); free(pid); free(vd);
+  } else if (precision == 16) {
+    /* the fp16-operand tower (agz_net_set_precision(F16)) restated: weights and tower activations
+     * rounded to half at exactly the points where the GPU stores / loads them, sums in float64 */
+    size_t nx = (size_t)B * 17 * n->P;
+    double* xd = (double*)malloc(sizeof(double) * nx);
+    double* pid = (double*)malloc(sizeof(double) * (size_t)B * n->A);
+    double* vd = (double*)malloc(sizeof(double) * (size_t)B);
+    for (size_t i = 0; i < nx; ++i) xd[i] = x[i];
+    forward_ex_f64(n, xd, B, pid, vd, 1);
     for (size_t i = 0; i < (size_t)B * n->A; ++i) pi[i] = (float)pid[i];
     for (int b = 0; b < B; ++b) v[b] = (float)vd[b];
     free(xd); free(pid); free(vd);

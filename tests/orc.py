@@ -155,6 +155,7 @@ def lib():
         "or_net_param_count": (C.c_int64, [vp, i, i]),
         "or_net_init_synthetic": (None, [vp, u64]),
         "or_net_forward_feats": (None, [vp, P(f), i, P(f), P(f), i]),
+        "or_quant_half": (C.c_float, [C.c_float]),
         "or_net_forward_feats_f64": (None, [vp, P(d), i, P(d), P(d)]),
         "or_net_callable": (None, [vp, P(P(OPos)), i, P(f), P(f)]),
         "or_set_num_threads": (None, [i]),
