@@ -32,8 +32,10 @@
 
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace agz {
 
@@ -235,6 +237,210 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16(const void* __restrict__ x,
       }
     }
   }
+}
+
+// ------------------------------------------------------------------ v2: everything staged by LDS-DMA
+//
+// The first version (above) moves the weights global -> VGPR -> LDS and tops out at ~10 B/clk/CU on
+// that stream; direct global->LDS DMA (global_load_lds_dwordx4, as in agz_wino.hip) sustains ~17 and
+// needs no staging registers.  Differences:
+//   weights   stored in HBM as ready-made padded tile images Wi[stage 72][256 rows][40 halves] (20 chunks of
+//             1 KB per stage), triple-buffered in LDS, two stages in flight, counted vmcnt
+//   slab      also by DMA: a lane may fetch from any global address but always writes LDS slot
+//             chunk*64 + lane, so the slab is stored unpadded (64 B rows) and bank conflicts are avoided
+//             by a swizzle applied on the SOURCE side: slot (row, p) holds piece p ^ ((row >> 2) & 3).
+//             Rows outside [0, M) are fetched from a clamped address: every use of them is masked.
+//   input     half only (the f32 stem output is converted once per forward)
+//   DMA issue interleaved between the MFMAs (see agz_wino.hip for why)
+constexpr int H2_BIMG = kC * HS;                      // halves per weight tile image (20,480 B)
+constexpr int H2_SLABCH = (HSLAB_MAX * 4 + 63) / 64;   // 19 chunks of 64 pieces
+size_t conv16_image_halves() { return (size_t)HCH * 9 * H2_BIMG; }
+
+void conv16_pack_images(const ConvHost& c, uint16_t* out) {
+  std::vector<uint16_t> w(conv16_weight_halves());
+  conv16_pack_weights(c, w.data());
+  for (int st = 0; st < HCH * 9; ++st)
+    for (int o = 0; o < kC; ++o)
+      for (int k = 0; k < HS; ++k)
+        out[((size_t)st * kC + o) * HS + k] = k < HK ? w[((size_t)st * kC + o) * HK + k] : 0;
+}
+
+__device__ __forceinline__ void glds16h(const void* g, unsigned lds_byte_addr) {
+  unsigned keep;
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds_byte_addr)
+      : "memory");
+}
+
+__global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restrict__ x, const uint16_t* __restrict__ wi,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const void* __restrict__ res, int res_f32, void* __restrict__ y,
+                                                          int out_f32, const int* __restrict__ d_count, int N, int relu) {
+  __shared__ __attribute__((aligned(16))) _Float16 sb[3][H2_BIMG];                 // 61,440 B
+  __shared__ __attribute__((aligned(16))) _Float16 sa[2][H2_SLABCH * 64 * 8];      // 38,912 B
+  const int P = N * N;
+  const long M = (long)(*d_count) * P;
+  const long m0 = (long)blockIdx.x * HM;
+  if (m0 >= M) return;
+  const int halo = N + 1, slab = HM + 2 * halo;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave & 3, wc = wave >> 2;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const unsigned sb0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)&sb[0][0];
+  const unsigned sa0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)&sa[0][0];
+  const int nslabch = (slab * 4 + 63) / 64;
+
+  // j-th weight chunk of this wave for `stage` into buffer `buf` (chunks wave, wave+8, wave+16 of 20)
+  auto dma_w = [&](int stage, int buf, int j) {
+    const int c = wave + 8 * j;
+    if (c >= 20) return;
+    glds16h(wi + (size_t)stage * H2_BIMG + c * 512 + lane * 8, sb0 + (unsigned)(buf * H2_BIMG + c * 512) * 2u);
+  };
+  // j-th slab chunk of this wave for channel chunk cc into slab buffer `buf`
+  auto dma_a = [&](int cc, int buf, int j) {
+    const int c = wave + 8 * j;
+    if (c >= nslabch) return;
+    const int slot = c * 64 + lane, s = slot >> 2, q = (slot & 3) ^ ((s >> 2) & 3);
+    long g = m0 - halo + s;
+    g = g < 0 ? 0 : (g >= M ? M - 1 : g);                 // out-of-range rows are only ever read masked
+    glds16h(x + g * kC + cc * HK + q * 8, sa0 + (unsigned)(buf * (H2_SLABCH * 512) + c * 512) * 2u);
+  };
+  const int nb = wave < 4 ? 3 : 2;                         // weight chunks this wave issues per stage
+
+  int srow[2];
+  unsigned vmask[2];
+#pragma unroll
+  for (int rbk = 0; rbk < 2; ++rbk) {
+    const int lr = wr * 64 + rbk * 32 + l31;
+    const long m = m0 + lr;
+    srow[rbk] = lr + halo;
+    unsigned mk = 0;
+    if (m < M) {
+      const int p = (int)(m % P), i = p % N, j = p / N;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int da = tap % 3 - 1, db = tap / 3 - 1;
+        if ((unsigned)(i + da) < (unsigned)N && (unsigned)(j + db) < (unsigned)N) mk |= 1u << tap;
+      }
+    }
+    vmask[rbk] = mk;
+  }
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  constexpr int NST = HCH * 9;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) dma_a(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) dma_w(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) dma_w(1, 1, j);
+  if (nb == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __syncthreads();
+
+  int buf = 0;
+  for (int st = 0; st < NST; ++st) {
+    const int cc = st / 9, tap = st - cc * 9;
+    const int nbuf = buf == 0 ? 2 : buf - 1;               // (st + 2) % 3
+    const bool more = st + 2 < NST;
+    const bool slab_now = tap == 7 && cc + 1 < HCH;        // the next chunk's slab: issued BEFORE this stage's weights
+    const _Float16* A = sa[cc & 1];
+    const _Float16* B = sb[buf];
+    const int off = (tap % 3 - 1) + N * (tap / 3 - 1);
+    h8 af[2][2], bf[2][4];                                 // [k-step][...]: both k-steps' operands up front
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int rbk = 0; rbk < 2; ++rbk) {
+        const int R = srow[rbk] + off;
+        const h8 v = *reinterpret_cast<const h8*>(A + (R * 4 + ((ks * 2 + hi) ^ ((R >> 2) & 3))) * 8);
+        const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        af[ks][rbk] = ((vmask[rbk] >> tap) & 1u) ? v : z;
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        bf[ks][cb] = *reinterpret_cast<const h8*>(B + (wc * 128 + cb * 32 + l31) * HS + ks * 16 + hi * 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int rbk = 0; rbk < 2; ++rbk) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][rbk], bf[ks][cb], acc[rbk][cb], 0, 0, 0);
+        // a DMA slot after every group of four MFMAs; all slab chunks are issued before the weights
+        // of st+2, so that the counted wait below covers them
+        const int slot = ks * 2 + rbk;
+        __builtin_amdgcn_sched_barrier(0);
+        if (slab_now && slot == 0) dma_a(cc + 1, (cc + 1) & 1, 0);
+        if (slab_now && slot == 1) { dma_a(cc + 1, (cc + 1) & 1, 1); dma_a(cc + 1, (cc + 1) & 1, 2); }
+        if (more && slot == 2) dma_w(st + 2, nbuf, 0);
+        if (more && slot == 3) { dma_w(st + 2, nbuf, 1); dma_w(st + 2, nbuf, 2); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    // this wave's chunks of stage st+1 (and any slab issued so far) have landed; st+2's may be in flight
+    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nb == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __syncthreads();
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int n = wc * 128 + cb * 32 + l31;
+    const float sc = scale[n], sh = shift[n];
+#pragma unroll
+    for (int rbk = 0; rbk < 2; ++rbk) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long m = m0 + wr * 64 + rbk * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (m < M) {
+          float v = acc[rbk][cb][e] * sc + sh;
+          if (res) v += res_f32 ? reinterpret_cast<const float*>(res)[m * kC + n]
+                                : (float)reinterpret_cast<const _Float16*>(res)[m * kC + n];
+          if (relu) v = fmaxf(v, 0.f);
+          if (out_f32) reinterpret_cast<float*>(y)[m * kC + n] = v;
+          else reinterpret_cast<_Float16*>(y)[m * kC + n] = (_Float16)v;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_f32_to_f16(const float* __restrict__ x, _Float16* __restrict__ y,
+                                                     const int* __restrict__ d_count, long per_position) {
+  const long n = (long)(*d_count) * per_position;        // multiple of 8
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
+    const float4 u = *reinterpret_cast<const float4*>(x + i), v = *reinterpret_cast<const float4*>(x + i + 4);
+    h8 h = {(_Float16)u.x, (_Float16)u.y, (_Float16)u.z, (_Float16)u.w, (_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    *reinterpret_cast<h8*>(y + i) = h;
+  }
+}
+
+void launch_f32_to_f16(const float* x, uint16_t* y, const int* d_count, int bcap, int N, hipStream_t s) {
+  const long n = (long)bcap * N * N * kC;
+  const int grid = (int)std::min<long>((n / 8 + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(k_f32_to_f16, dim3(grid), dim3(256), 0, s, x, (_Float16*)y, d_count, (long)N * N * kC);
+}
+
+void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale, const float* shift, const void* res,
+                       int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
+  const long rows = (long)bcap * N * N;
+  const int grid = (int)((rows + HM - 1) / HM);
+  hipLaunchKernelGGL(k_conv3x3_f16_dma, dim3(grid), dim3(512), 0, s, (const _Float16*)x, wi, scale, shift, res, res_f32,
+                     y, out_f32, d_count, N, relu);
 }
 
 void launch_conv16(const void* x, int in_f32, const uint16_t* wh, const float* scale, const float* shift,

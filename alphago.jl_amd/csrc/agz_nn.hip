@@ -480,6 +480,12 @@ void Net::pack() {
     d_wh16_.ensure(w.size());
     AGZ_HIP(hipMemcpyAsync(d_wh16_.p, w.data(), w.size() * sizeof(uint16_t), hipMemcpyHostToDevice, stream_));
     AGZ_HIP(hipStreamSynchronize(stream_));
+    const size_t iper = conv16_image_halves();
+    std::vector<uint16_t> wi(iper * 2 * tower_);
+    for (int l = 0; l < 2 * tower_; ++l) conv16_pack_images(tconv_[l], wi.data() + iper * l);
+    d_wi16_.ensure(wi.size());
+    AGZ_HIP(hipMemcpyAsync(d_wi16_.p, wi.data(), wi.size() * sizeof(uint16_t), hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
     packed16_ = true;
   }
   if (!dirty_) return;
@@ -569,11 +575,32 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
   if (precision_ == 1 && tower_ > 0) {
     // fp16 tower: the first conv reads the f32 stem output (rounded on load), the last one writes
     // f32 for the heads; everything in between lives in half buffers
-    const size_t hper = conv16_weight_halves();
+    const size_t hper = conv16_weight_halves(), iper = conv16_image_halves();
+    static const bool v1 = getenv("AGZ_C16_V1") != nullptr;     // A/B switch: register-staged first version
     const void* cur = a;          // block input (f32 for block 0, half afterwards)
     int cur_f32 = 1;
     uint16_t *ha = d_ha_.p, *hb = d_hb_.p;
-    for (int blk = 0; blk < tower_; ++blk) {
+    if (!v1) launch_f32_to_f16(a, hb, d_count, bcap, N_, stream_);   // the DMA kernel reads half only
+    for (int blk = 0; blk < tower_ && !v1; ++blk) {
+      const int l1 = 2 * blk, l2 = 2 * blk + 1;
+      const bool last = blk + 1 == tower_;
+      const uint16_t* in1 = blk == 0 ? hb : (const uint16_t*)cur;
+      const bool p1 = prof_on_ && prof_n_ < kProfMax;
+      if (p1) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+      launch_conv16_dma(in1, d_wi16_.p + iper * l1, d_scale_.p + (size_t)(l1 + 1) * kC,
+                        d_shift_.p + (size_t)(l1 + 1) * kC, nullptr, 0, d_ht_.p, 0, d_count, bcap, N_, 1, stream_);
+      if (p1) { (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_); prof_fwd_of_[prof_n_++] = prof_fwd_; }
+      const bool p2 = prof_on_ && prof_n_ < kProfMax;
+      if (p2) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+      void* out = last ? (void*)b : (void*)ha;
+      launch_conv16_dma(d_ht_.p, d_wi16_.p + iper * l2, d_scale_.p + (size_t)(l2 + 1) * kC,
+                        d_shift_.p + (size_t)(l2 + 1) * kC, cur, cur_f32, out, last ? 1 : 0, d_count, bcap, N_, 1, stream_);
+      if (p2) { (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_); prof_fwd_of_[prof_n_++] = prof_fwd_; }
+      cur = ha;
+      cur_f32 = 0;
+      std::swap(ha, hb);
+    }
+    for (int blk = 0; blk < tower_ && v1; ++blk) {
       const int l1 = 2 * blk, l2 = 2 * blk + 1;
       const bool last = blk + 1 == tower_;
       const bool p1 = prof_on_ && prof_n_ < kProfMax;
@@ -666,9 +693,12 @@ void Net::launch_tower_conv_once(const int* d_count, int bcap) {
   reserve(bcap);
   AGZ_REQUIRE(tower_ > 0, AGZ_BAD_ARGUMENT, "no tower conv in a tower_height=0 network");
   const int grid = conv_grid(bcap, P_);
-  if (precision_ == 1)
+  if (precision_ == 1 && getenv("AGZ_C16_V1"))
     launch_conv16(d_ha_.p, 0, d_wh16_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, 0, d_ht_.p, 0, d_count, bcap, N_, 1,
                   stream_);
+  else if (precision_ == 1)
+    launch_conv16_dma(d_ha_.p, d_wi16_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, 0, d_ht_.p, 0, d_count, bcap, N_, 1,
+                      stream_);
   else if (winograd_)
     launch_wino_conv(d_a_.p, d_vimg_.p, d_uwino_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, d_t_.p, d_count, bcap,
                      N_, 1, stream_);
