@@ -275,6 +275,7 @@ __device__ __forceinline__ void glds16h(const void* g, unsigned lds_byte_addr) {
       : "memory");
 }
 
+template <int DBG>   // timing experiments only: 0 = product; 1 = no MFMA; 2 = no DMA in the loop; 3 = no LDS reads; 4 = no main loop; 5 = no epilogue
 __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restrict__ x, const uint16_t* __restrict__ wi,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const void* __restrict__ res, int res_f32, void* __restrict__ y,
@@ -350,11 +351,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
   __syncthreads();
 
   int buf = 0;
-  for (int st = 0; st < NST; ++st) {
+  for (int st = 0; st < (DBG == 4 ? 0 : NST); ++st) {
     const int cc = st / 9, tap = st - cc * 9;
     const int nbuf = buf == 0 ? 2 : buf - 1;               // (st + 2) % 3
-    const bool more = st + 2 < NST;
-    const bool slab_now = tap == 7 && cc + 1 < HCH;        // the next chunk's slab: issued BEFORE this stage's weights
+    const bool more = st + 2 < NST && DBG != 2;
+    const bool slab_now = tap == 7 && cc + 1 < HCH && DBG != 2;   // the next chunk's slab: issued BEFORE this stage's weights
     const _Float16* A = sa[cc & 1];
     const _Float16* B = sb[buf];
     const int off = (tap % 3 - 1) + N * (tap / 3 - 1);
@@ -367,10 +368,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
         const h8 v = *reinterpret_cast<const h8*>(A + (R * 4 + ((ks * 2 + hi) ^ ((R >> 2) & 3))) * 8);
         const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         af[ks][rbk] = ((vmask[rbk] >> tap) & 1u) ? v : z;
+        if (DBG == 3) af[ks][rbk] = h8{(_Float16)1, (_Float16)2, (_Float16)st, 0, 0, 0, 0, (_Float16)lane};
       }
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
-        bf[ks][cb] = *reinterpret_cast<const h8*>(B + (wc * 128 + cb * 32 + l31) * HS + ks * 16 + hi * 8);
+        bf[ks][cb] = DBG == 3 ? h8{(_Float16)1, (_Float16)cb, (_Float16)st, 0, 0, 0, 0, (_Float16)lane}
+                              : *reinterpret_cast<const h8*>(B + (wc * 128 + cb * 32 + l31) * HS + ks * 16 + hi * 8);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -378,7 +381,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
       for (int rbk = 0; rbk < 2; ++rbk) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
-          acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][rbk], bf[ks][cb], acc[rbk][cb], 0, 0, 0);
+          if (DBG != 1) acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][rbk], bf[ks][cb], acc[rbk][cb], 0, 0, 0);
+          else acc[rbk][cb][0] += (float)af[ks][rbk][0] + (float)bf[ks][cb][1];
         // a DMA slot after every group of four MFMAs; all slab chunks are issued before the weights
         // of st+2, so that the counted wait below covers them
         const int slot = ks * 2 + rbk;
@@ -395,6 +399,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __syncthreads();
     buf = buf == 2 ? 0 : buf + 1;
+  }
+  if (DBG == 5) {
+    float keep = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) keep += acc[a][b][0] + acc[a][b][15];
+    if (keep == 123.456f) reinterpret_cast<float*>(y)[0] = keep;
+    return;
   }
 
 #pragma unroll
@@ -439,7 +452,9 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
                        int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
   const long rows = (long)bcap * N * N;
   const int grid = (int)((rows + HM - 1) / HM);
-  hipLaunchKernelGGL(k_conv3x3_f16_dma, dim3(grid), dim3(512), 0, s, (const _Float16*)x, wi, scale, shift, res, res_f32,
+  static const int dbg = getenv("AGZ_C16_DEBUG") ? atoi(getenv("AGZ_C16_DEBUG")) : 0;   // timing experiments only
+  auto kern = dbg == 1 ? k_conv3x3_f16_dma<1> : dbg == 2 ? k_conv3x3_f16_dma<2> : dbg == 3 ? k_conv3x3_f16_dma<3> : dbg == 4 ? k_conv3x3_f16_dma<4> : dbg == 5 ? k_conv3x3_f16_dma<5> : k_conv3x3_f16_dma<0>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, (const _Float16*)x, wi, scale, shift, res, res_f32,
                      y, out_f32, d_count, N, relu);
 }
 
