@@ -4,28 +4,32 @@
 //
 // Implicit GEMM, M = B*N^2 board points, N = 256 couts, K = 9*256 ordered (cin chunk, tap, cin).
 // What makes it different from the f32 direct kernel (agz_nn.hip) is where the nine taps come from:
-// a workgroup owns 256 consecutive rows and ALL 256 output channels, stages the 32-channel slab of
-// its rows plus a halo of N+1 rows on either side in LDS ONCE per channel chunk, and the nine taps
-// read that slab at nine row offsets (a lane whose neighbour is off the board multiplies zeros).
-// Activations are therefore fetched once instead of nine times, and the weights -- 16 KB per
+// a workgroup owns 256 consecutive rows and ALL 256 output channels, brings the 32-channel slab of
+// its rows plus a halo of N+1 rows on either side into LDS ONCE per channel chunk, and the nine taps
+// read that slab at nine row offsets (a lane whose neighbour is off the board selects zeros).
+// Activations are therefore fetched once instead of nine times, and the weights -- 20 KB per
 // (chunk, tap) -- are the only per-stage stream.  fp16 MFMA is 16x the f32 rate, so everything
 // around it has to move that much less.
 //
-//   tower activations  [M][256] half in HBM (the first conv may read the f32 stem output, the last
-//                      one writes f32 for the heads; residuals in either type)
-//   weights            Wh[chunk 8][tap 9][cout 256][32] half, true-convolution flip applied at pack time
+//   tower activations  [M][256] half in HBM (the f32 stem output is converted once per forward; the
+//                      last conv writes f32 for the heads; residuals in either type)
 //   workgroup          512 threads = 8 waves = 4 row groups (64 rows) x 2 cout halves (128);
 //                      a wave holds 2 x 4 accumulator tiles of 32x32 (128 VGPRs)
-//   LDS                A slab (256 + 2(N+1) rows) and B tile (256 rows), 32 halves per row padded to 40
-//                      (80 B: the 16 rows of a ds_read_b128 phase fall on 16 distinct 16-B bank groups),
-//                      both double-buffered: 88 KB
-//   a stage            one (chunk, tap): 2 k-steps x 8 MFMAs per wave; the weights of stage st+2 are
-//                      loaded to registers before the MFMAs of stage st, those of st+1 are written to
-//                      the other LDS buffer after them; one barrier per stage
-//   status             first version: 1.2 ms per layer at 8192 positions (0.31 ms of MFMA time).  Timing
-//                      modes (AGZ_C16_DEBUG) put the loss on the weight stream: global->VGPR->LDS runs at
-//                      ~10 B/clk/CU, 49 us per 256-row tile against 31 us of MFMAs; next step is LDS-DMA
-//                      staging with ready-made tile images, as in agz_wino.hip
+//   weights            stored in HBM as ready-made padded LDS tile images Wi[stage 72][256 rows][40 halves]
+//                      (80 B rows: the 16 rows of a ds_read_b128 phase fall on 16 distinct 16-B bank
+//                      groups), true-convolution flip applied at pack time; brought in by LDS-DMA
+//                      (global_load_lds_dwordx4), triple-buffered, two stages in flight, counted vmcnt
+//   slab               also by DMA: a lane may fetch from any global address but always writes LDS slot
+//                      chunk*64 + lane, so the slab is stored unpadded (64 B rows) and bank conflicts are
+//                      avoided by a swizzle applied on the SOURCE side: slot (row, p) holds piece
+//                      p ^ ((row >> 2) & 3).  Rows outside [0, M) are fetched from a clamped address:
+//                      every use of them is masked.
+//   a stage            one (chunk, tap): 2 k-steps x 8 MFMAs per wave, both k-steps' operands read up
+//                      front, the DMA instructions interleaved between the MFMAs (see agz_wino.hip for
+//                      why), one barrier per stage
+//   epilogue           half-in/half-out layers stage their tile through LDS so that residual and result
+//                      move as 16-byte pieces of whole rows (2-byte scatters cost 0.27 ms per layer)  A first version that moved the
+//                      weights global -> VGPR -> LDS topped out at ~10 B/clk/CU on that stream (1.19 ms).
 // The reduction order of an output is fixed (chunk, tap, k) and does not depend on where its row
 // sits in the batch: tree parity with the oracle (which calls this network) stays bit-exact.
 #include "agz_nn.h"
@@ -49,11 +53,11 @@ constexpr int HS = HK + 8;         // LDS row stride (halves)
 constexpr int HCH = kC / HK;       // 8 chunks
 constexpr int HSLAB_MAX = HM + 2 * (19 + 1);   // 296 rows
 
-size_t conv16_weight_halves() { return (size_t)HCH * 9 * kC * HK; }
+static size_t conv16_weight_halves() { return (size_t)HCH * 9 * kC * HK; }
 
 // Wh[chunk][tap][cout][32]; tap reads x[row + da, col + db] with da = tap % 3 - 1, db = tap / 3 - 1 and
 // multiplies Flux's w[a = 1 - da, b = 1 - db] (NNlib true convolution), as in pack_conv3 (agz_nn.hip)
-void conv16_pack_weights(const ConvHost& c, uint16_t* out) {
+static void conv16_pack_weights(const ConvHost& c, uint16_t* out) {
   for (int cc = 0; cc < HCH; ++cc)
     for (int a = 0; a < 3; ++a)
       for (int b = 0; b < 3; ++b) {
@@ -67,191 +71,6 @@ void conv16_pack_weights(const ConvHost& c, uint16_t* out) {
       }
 }
 
-__device__ __forceinline__ uint4 load_row_piece(const void* x, int in_f32, long row, int col_half) {
-  // 8 consecutive channels of one activation row as 8 halves
-  if (in_f32) {
-    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + row * kC + col_half);
-    const float4 u = p[0], v = p[1];
-    h8 h = {(_Float16)u.x, (_Float16)u.y, (_Float16)u.z, (_Float16)u.w,
-            (_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-    return *reinterpret_cast<uint4*>(&h);
-  }
-  return *reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(x) + row * kC + col_half);
-}
-
-template <int DBG>   // timing experiments only: 0 = product; 1 = no MFMA; 2 = operands from constants (no LDS reads); 3 = no weight refill
-__global__ __launch_bounds__(512) void k_conv3x3_f16(const void* __restrict__ x, int in_f32,
-                                                      const uint16_t* __restrict__ wh,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      const void* __restrict__ res, int res_f32, void* __restrict__ y,
-                                                      int out_f32, const int* __restrict__ d_count, int N, int relu) {
-  __shared__ __attribute__((aligned(16))) _Float16 sa[2][HSLAB_MAX * HS];
-  __shared__ __attribute__((aligned(16))) _Float16 sb[2][kC * HS];
-  const int P = N * N;
-  const long M = (long)(*d_count) * P;
-  const long m0 = (long)blockIdx.x * HM;
-  if (m0 >= M) return;
-  const int halo = N + 1, slab = HM + 2 * halo;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave & 3, wc = wave >> 2;
-  const int l31 = lane & 31, hi = lane >> 5;
-
-  // staging assignments: slab = `slab` rows x 4 pieces of 8 halves, weights = 256 rows x 4 pieces
-  uint4 ra[3], rb[2][2];     // rb[set][piece]: the weights of the next two stages are in flight
-  auto load_slab = [&](int cc) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int q = tid + 512 * i, s = q >> 2, pc = q & 3;
-      const long g = m0 - halo + s;
-      ra[i] = (s < slab && g >= 0 && g < M) ? load_row_piece(x, in_f32, g, cc * HK + pc * 8) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto store_slab = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int q = tid + 512 * i, s = q >> 2, pc = q & 3;
-      if (s < slab) *reinterpret_cast<uint4*>(&sa[buf][s * HS + pc * 8]) = ra[i];
-    }
-  };
-  auto load_w = [&](int stage, uint4* r) {   // stage = chunk * 9 + tap: a contiguous 16 KB tile
-    const uint4* src = reinterpret_cast<const uint4*>(wh + (size_t)stage * kC * HK);
-    r[0] = src[tid];
-    r[1] = src[tid + 512];
-  };
-  auto store_w = [&](int buf, const uint4* r) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = tid + 512 * i, o = q >> 2, pc = q & 3;
-      *reinterpret_cast<uint4*>(&sb[buf][o * HS + pc * 8]) = r[i];
-    }
-  };
-
-  // this lane's two output rows: slab row and which of the nine neighbours exist
-  int srow[2];
-  unsigned vmask[2];
-#pragma unroll
-  for (int rbk = 0; rbk < 2; ++rbk) {
-    const int lr = wr * 64 + rbk * 32 + l31;
-    const long m = m0 + lr;
-    srow[rbk] = lr + halo;
-    unsigned mk = 0;
-    if (m < M) {
-      const int p = (int)(m % P), i = p % N, j = p / N;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int da = tap % 3 - 1, db = tap / 3 - 1;
-        if ((unsigned)(i + da) < (unsigned)N && (unsigned)(j + db) < (unsigned)N) mk |= 1u << tap;
-      }
-    }
-    vmask[rbk] = mk;
-  }
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  load_slab(0);
-  load_w(0, rb[0]);
-  store_slab(0);
-  store_w(0, rb[0]);
-  load_w(1, rb[1]);          // stage 1's weights: stored at the end of stage 0
-  __syncthreads();
-
-  // One stage = one (chunk, tap): 2 k-steps x 8 MFMAs per wave.  Global loads are issued TWO stages
-  // ahead of their use: at stage st the weights of st+2 start their trip into register set st&1, the
-  // set (st+1)&1 -- loaded a stage ago -- goes to LDS after the MFMAs.  The activation slab of the
-  // next channel chunk is fetched during tap 7 and stored after tap 8.
-  constexpr int NST = HCH * 9;
-  auto stage = [&](auto PAR, int st) {
-    constexpr int par = decltype(PAR)::value;
-    const int cc = st / 9, tap = st - cc * 9;
-    if (st + 2 < NST && DBG != 3) load_w(st + 2, rb[par]);
-    if (tap == 7 && cc + 1 < HCH) load_slab(cc + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const _Float16* A = sa[cc & 1];
-    const _Float16* B = sb[par];
-    const int off = (tap % 3 - 1) + N * (tap / 3 - 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      h8 af[2], bf[4];
-#pragma unroll
-      for (int rbk = 0; rbk < 2; ++rbk) {
-        const h8 v = *reinterpret_cast<const h8*>(A + (srow[rbk] + off) * HS + ks * 16 + hi * 8);
-        const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        af[rbk] = ((vmask[rbk] >> tap) & 1u) ? v : z;
-        if (DBG == 2) af[rbk] = h8{(_Float16)1, (_Float16)2, (_Float16)st, 0, 0, 0, 0, (_Float16)lane};
-      }
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-        bf[cb] = DBG == 2 ? h8{(_Float16)1, (_Float16)cb, (_Float16)st, 0, 0, 0, 0, (_Float16)lane}
-                          : *reinterpret_cast<const h8*>(B + (wc * 128 + cb * 32 + l31) * HS + ks * 16 + hi * 8);
-#pragma unroll
-      for (int rbk = 0; rbk < 2; ++rbk)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-          if (DBG != 1) acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rbk], bf[cb], acc[rbk][cb], 0, 0, 0);
-          else acc[rbk][cb][0] += (float)af[rbk][0] + (float)bf[cb][1];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (st + 1 < NST && DBG != 3) store_w(par ^ 1, rb[par ^ 1]);
-    if (tap == 8 && cc + 1 < HCH) store_slab((cc + 1) & 1);
-    __syncthreads();
-  };
-  for (int st = 0; st < (DBG == 4 ? 0 : NST); st += 2) {
-    stage(std::integral_constant<int, 0>{}, st);
-    stage(std::integral_constant<int, 1>{}, st + 1);
-  }
-
-  if (DBG == 5) {   // timing: no epilogue
-    float keep = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) keep += acc[a][b][0] + acc[a][b][15];
-    if (keep == 123.456f) reinterpret_cast<float*>(y)[0] = keep;
-    return;
-  }
-  // epilogue: y = act(scale*acc + shift (+ residual)); C/D map of the 32x32 MFMA:
-  // col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
-#pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
-    const int n = wc * 128 + cb * 32 + l31;
-    const float sc = scale[n], sh = shift[n];
-#pragma unroll
-    for (int rbk = 0; rbk < 2; ++rbk) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const long m = m0 + wr * 64 + rbk * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        if (m < M) {
-          float v = acc[rbk][cb][e] * sc + sh;
-          if (res) v += res_f32 ? reinterpret_cast<const float*>(res)[m * kC + n]
-                                : (float)reinterpret_cast<const _Float16*>(res)[m * kC + n];
-          if (relu) v = fmaxf(v, 0.f);
-          if (out_f32) reinterpret_cast<float*>(y)[m * kC + n] = v;
-          else reinterpret_cast<_Float16*>(y)[m * kC + n] = (_Float16)v;
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------ v2: everything staged by LDS-DMA
-//
-// The first version (above) moves the weights global -> VGPR -> LDS and tops out at ~10 B/clk/CU on
-// that stream; direct global->LDS DMA (global_load_lds_dwordx4, as in agz_wino.hip) sustains ~17 and
-// needs no staging registers.  Differences:
-//   weights   stored in HBM as ready-made padded tile images Wi[stage 72][256 rows][40 halves] (20 chunks of
-//             1 KB per stage), triple-buffered in LDS, two stages in flight, counted vmcnt
-//   slab      also by DMA: a lane may fetch from any global address but always writes LDS slot
-//             chunk*64 + lane, so the slab is stored unpadded (64 B rows) and bank conflicts are avoided
-//             by a swizzle applied on the SOURCE side: slot (row, p) holds piece p ^ ((row >> 2) & 3).
-//             Rows outside [0, M) are fetched from a clamped address: every use of them is masked.
-//   input     half only (the f32 stem output is converted once per forward)
-//   DMA issue interleaved between the MFMAs (see agz_wino.hip for why)
 constexpr int H2_BIMG = kC * HS;                      // halves per weight tile image (20,480 B)
 constexpr int H2_SLABCH = (HSLAB_MAX * 4 + 63) / 64;   // 19 chunks of 64 pieces
 size_t conv16_image_halves() { return (size_t)HCH * 9 * H2_BIMG; }
@@ -280,8 +99,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const void* __restrict__ res, int res_f32, void* __restrict__ y,
                                                           int out_f32, const int* __restrict__ d_count, int N, int relu) {
-  __shared__ __attribute__((aligned(16))) _Float16 sb[3][H2_BIMG];                 // 61,440 B
-  __shared__ __attribute__((aligned(16))) _Float16 sa[2][H2_SLABCH * 64 * 8];      // 38,912 B
+  // one LDS block: 3 weight tile images (61,440 B) + 2 slab buffers (38,912 B); the epilogue reuses it
+  __shared__ __attribute__((aligned(16))) _Float16 smem[3 * H2_BIMG + 2 * H2_SLABCH * 512];
+  _Float16(*sb)[H2_BIMG] = reinterpret_cast<_Float16(*)[H2_BIMG]>(smem);
+  _Float16(*sa)[H2_SLABCH * 512] = reinterpret_cast<_Float16(*)[H2_SLABCH * 512]>(smem + 3 * H2_BIMG);
   const int P = N * N;
   const long M = (long)(*d_count) * P;
   const long m0 = (long)blockIdx.x * HM;
@@ -291,8 +112,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave & 3, wc = wave >> 2;
   const int l31 = lane & 31, hi = lane >> 5;
-  const unsigned sb0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)&sb[0][0];
-  const unsigned sa0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)&sa[0][0];
+  const unsigned sb0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)&smem[0];
+  const unsigned sa0 = sb0 + 3u * H2_BIMG * 2u;
   const int nslabch = (slab * 4 + 63) / 64;
 
   // j-th weight chunk of this wave for `stage` into buffer `buf` (chunks wave, wave+8, wave+16 of 20)
@@ -410,17 +231,65 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
     return;
   }
 
+  // epilogue: y = act(scale*acc + shift (+ residual)).  C/D map of the 32x32 MFMA: col = lane & 31,
+  // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) -- a lane holds single couts of 16 rows, which as
+  // half stores would be 2-byte scatters (0.27 ms per layer).  Half-in/half-out layers therefore go
+  // through a wave-private LDS tile [32 rows][128 couts]: the residual arrives and the result leaves
+  // as 16-byte pieces of whole rows.  (The f32 residual of block 0 and the f32 output of the last
+  // layer keep the direct path: two layers of twenty.)
+  float sc[4], sh[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    sc[cb] = scale[wc * 128 + cb * 32 + l31];
+    sh[cb] = shift[wc * 128 + cb * 32 + l31];
+  }
+  if (!out_f32 && !(res && res_f32)) {
+    constexpr int TS = 128 + 8;                                  // tile row stride (halves)
+    _Float16* T = smem + wave * (32 * TS);
+    const _Float16* rh = reinterpret_cast<const _Float16*>(res);
+    _Float16* yh = reinterpret_cast<_Float16*>(y);
+#pragma unroll
+    for (int rbk = 0; rbk < 2; ++rbk) {
+      const long mrow0 = m0 + wr * 64 + rbk * 32;
+      if (res) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                            // 32 rows x 16 pieces of 8 halves
+          const int pc = lane + 64 * i, r = pc >> 4, c8 = (pc & 15) * 8;
+          const long m = mrow0 + r;
+          const uint4 v = m < M ? *reinterpret_cast<const uint4*>(rh + m * kC + wc * 128 + c8) : make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(T + r * TS + c8) = v;
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = (e & 3) + 8 * (e >> 2) + 4 * hi;
+          _Float16* t = T + r * TS + cb * 32 + l31;
+          float v = acc[rbk][cb][e] * sc[cb] + sh[cb];
+          if (res) v += (float)*t;
+          if (relu) v = fmaxf(v, 0.f);
+          *t = (_Float16)v;
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pc = lane + 64 * i, r = pc >> 4, c8 = (pc & 15) * 8;
+        const long m = mrow0 + r;
+        if (m < M) *reinterpret_cast<uint4*>(yh + m * kC + wc * 128 + c8) = *reinterpret_cast<const uint4*>(T + r * TS + c8);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     const int n = wc * 128 + cb * 32 + l31;
-    const float sc = scale[n], sh = shift[n];
 #pragma unroll
     for (int rbk = 0; rbk < 2; ++rbk) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const long m = m0 + wr * 64 + rbk * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
         if (m < M) {
-          float v = acc[rbk][cb][e] * sc + sh;
+          float v = acc[rbk][cb][e] * sc[cb] + sh[cb];
           if (res) v += res_f32 ? reinterpret_cast<const float*>(res)[m * kC + n]
                                 : (float)reinterpret_cast<const _Float16*>(res)[m * kC + n];
           if (relu) v = fmaxf(v, 0.f);
@@ -456,17 +325,6 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   auto kern = dbg == 1 ? k_conv3x3_f16_dma<1> : dbg == 2 ? k_conv3x3_f16_dma<2> : dbg == 3 ? k_conv3x3_f16_dma<3> : dbg == 4 ? k_conv3x3_f16_dma<4> : dbg == 5 ? k_conv3x3_f16_dma<5> : k_conv3x3_f16_dma<0>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, (const _Float16*)x, wi, scale, shift, res, res_f32,
                      y, out_f32, d_count, N, relu);
-}
-
-void launch_conv16(const void* x, int in_f32, const uint16_t* wh, const float* scale, const float* shift,
-                   const void* res, int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu,
-                   hipStream_t s) {
-  const long rows = (long)bcap * N * N;
-  const int grid = (int)((rows + HM - 1) / HM);
-  static const int dbg = getenv("AGZ_C16_DEBUG") ? atoi(getenv("AGZ_C16_DEBUG")) : 0;   // timing experiments only
-  auto kern = dbg == 1 ? k_conv3x3_f16<1> : dbg == 2 ? k_conv3x3_f16<2> : dbg == 3 ? k_conv3x3_f16<3> : dbg == 4 ? k_conv3x3_f16<4> : dbg == 5 ? k_conv3x3_f16<5> : k_conv3x3_f16<0>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, x, in_f32, wh, scale, shift, res, res_f32, y, out_f32,
-                     d_count, N, relu);
 }
 
 }  // namespace agz

@@ -85,8 +85,7 @@ class Net {
   DevBuf<float> d_uwino_, d_vimg_;        // transformed weights (stage images) / transformed activations
   int precision_ = 0;
   bool packed16_ = false;
-  DevBuf<uint16_t> d_wh16_;               // fp16 tower weights [layer][chunk][tap][cout][32]
-  DevBuf<uint16_t> d_wi16_;               // the same as padded LDS tile images [layer][stage][256][40]
+  DevBuf<uint16_t> d_wi16_;               // fp16 tower weights as padded LDS tile images [layer][stage 72][256][40]
   DevBuf<uint16_t> d_ha_, d_hb_, d_ht_;   // fp16 tower activations [rows][256]
   // profiling
   bool prof_on_ = false;
@@ -104,17 +103,12 @@ size_t wino_v_floats(int bcap, int T);
 void launch_wino_conv(const float* x, float* vimg, const float* uimg, const float* scale, const float* shift,
                       const float* res, float* y, const int* d_count, int bcap, int N, int relu, hipStream_t s);
 
-// fp16-operand tower convolution (agz_conv16.hip); x / res / y are float* or half* as flagged
-void conv16_pack_weights(const ConvHost& c, uint16_t* out);
-size_t conv16_weight_halves();
+// fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged
 void conv16_pack_images(const ConvHost& c, uint16_t* out);
 size_t conv16_image_halves();
 void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale, const float* shift, const void* res,
                        int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s);
 void launch_f32_to_f16(const float* x, uint16_t* y, const int* d_count, int bcap, int N, hipStream_t s);
-void launch_conv16(const void* x, int in_f32, const uint16_t* wh, const float* scale, const float* shift,
-                   const void* res, int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu,
-                   hipStream_t s);
 
 // feature extraction entry points (features.jl:3-26) from the reference's own position format
 void launch_features_from_deltas(const int8_t* d_boards, const int8_t* d_deltas, const int32_t* d_ndeltas,
