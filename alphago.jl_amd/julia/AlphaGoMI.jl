@@ -430,6 +430,10 @@ function copy_weights!(dst::Engine, src::Engine)
   dst
 end
 
+# tower arithmetic of an engine's network: :f32 (default, exact) or :f16 (fp16 operands, f32 accumulate)
+set_precision!(e::Engine, p::Symbol) =
+  check(e, ccall((:agz_net_set_precision, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, p === :f16 ? 1 : 0))
+
 # ------------------------------------------------------------------ evaluate
 # evaluate(env, black_net, white_net; num_games, ro), src/neural_net.jl:103-158: both networks live
 # in one arena_mode engine (network 0 = Black's, 1 = White's), every game is a pair of slots, all
