@@ -227,6 +227,7 @@ def main():
             },
             "positions": d["positions"], "evals": d["evals"],
             "evals_per_position": d["evals"] / max(d["positions"], 1),
+            "duplicate_evals": d["duplicate_evals"], "terminal_visits": d["terminal_visits"],
             "readout_positions_per_s": d["root_visits"] / R / elapsed,
             "games_finished": d["games_finished"],
             "end_to_end_mfma_frac": value * fpos / (world * peak * 1e12),

@@ -69,6 +69,7 @@ def test_external_network_games_match_oracle(N, tower, readouts, games, slots):
     (5, 2, 16, 12, 5, dict(resign_threshold=-0.05, resign_disable_fraction=0.5)),
     (9, 2, 32, 3, 3, {}),
     (19, 1, 8, 2, 2, {}),                                   # full-size board (BASELINE configs[3] shape, shortened)
+    (9, 10, 400, 1, 1, {}),                                 # BASELINE configs[1] network and readout budget, one whole game
 ])
 def test_internal_network_games_match_oracle(N, tower, readouts, games, slots, kw):
     eng = ag.Engine(board_size=N, tower_height=tower, games=slots, num_readouts=readouts, seed=2,
