@@ -94,18 +94,29 @@ __device__ __forceinline__ void glds16h(const void* g, unsigned lds_byte_addr) {
       : "memory");
 }
 
-template <int DBG>   // timing experiments only: 0 = product; 1 = no MFMA; 2 = no DMA in the loop; 3 = no LDS reads; 4 = no main loop; 5 = no epilogue
-__global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restrict__ x, const uint16_t* __restrict__ wi,
+// CH = output channels per workgroup: 256 (8 waves, one workgroup per CU) or 128 (4 waves, TWO workgroups
+// per CU: one's barriers, prologue and epilogue hide behind the other's MFMAs).
+// DBG: timing experiments only: 0 = product; 1 = no MFMA; 2 = no DMA in the loop; 3 = no LDS reads; 4 = no main loop; 5 = no epilogue
+template <int DBG, int CH>
+__global__ __launch_bounds__(CH / 32 * 64, CH == 128 ? 2 : 1) void k_conv3x3_f16_dma(const _Float16* __restrict__ x, const uint16_t* __restrict__ wi,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const void* __restrict__ res, int res_f32, void* __restrict__ y,
                                                           int out_f32, const int* __restrict__ d_count, int N, int relu) {
-  // one LDS block: 3 weight tile images (61,440 B) + 2 slab buffers (38,912 B); the epilogue reuses it
-  __shared__ __attribute__((aligned(16))) _Float16 smem[3 * H2_BIMG + 2 * H2_SLABCH * 512];
-  _Float16(*sb)[H2_BIMG] = reinterpret_cast<_Float16(*)[H2_BIMG]>(smem);
-  _Float16(*sa)[H2_SLABCH * 512] = reinterpret_cast<_Float16(*)[H2_SLABCH * 512]>(smem + 3 * H2_BIMG);
+  constexpr int NWAVE = CH / 32, BIMG = CH * HS, NCHW = BIMG / 512;   // waves; halves / 1 KB chunks per weight tile
+  // one LDS block: 3 weight tile images + 2 slab buffers (100,352 B / 69,632 B); the epilogue reuses it
+  __shared__ __attribute__((aligned(16))) _Float16 smem[3 * BIMG + 2 * H2_SLABCH * 512];
+  _Float16(*sb)[BIMG] = reinterpret_cast<_Float16(*)[BIMG]>(smem);
+  _Float16(*sa)[H2_SLABCH * 512] = reinterpret_cast<_Float16(*)[H2_SLABCH * 512]>(smem + 3 * BIMG);
   const int P = N * N;
   const long M = (long)(*d_count) * P;
-  const long m0 = (long)blockIdx.x * HM;
+  // consecutive logical workgroups (the cout halves of one row tile, then the next row tile) run on the
+  // same XCD and share its L2 copy of the slab: block b runs on XCD b % 8
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int NCB = kC / CH;
+  const long m0 = (long)(lid / NCB) * HM;
+  const int n0 = (lid % NCB) * CH;
   if (m0 >= M) return;
   const int halo = N + 1, slab = HM + 2 * halo;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -113,25 +124,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
   const int wr = wave & 3, wc = wave >> 2;
   const int l31 = lane & 31, hi = lane >> 5;
   const unsigned sb0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)&smem[0];
-  const unsigned sa0 = sb0 + 3u * H2_BIMG * 2u;
+  const unsigned sa0 = sb0 + 3u * BIMG * 2u;
   const int nslabch = (slab * 4 + 63) / 64;
 
-  // j-th weight chunk of this wave for `stage` into buffer `buf` (chunks wave, wave+8, wave+16 of 20)
+  // j-th weight chunk of this wave for `stage` into buffer `buf` (chunks wave, wave+NWAVE, ... of NCHW)
   auto dma_w = [&](int stage, int buf, int j) {
-    const int c = wave + 8 * j;
-    if (c >= 20) return;
-    glds16h(wi + (size_t)stage * H2_BIMG + c * 512 + lane * 8, sb0 + (unsigned)(buf * H2_BIMG + c * 512) * 2u);
+    const int c = wave + NWAVE * j;
+    if (c >= NCHW) return;
+    glds16h(wi + (size_t)stage * H2_BIMG + n0 * HS + c * 512 + lane * 8, sb0 + (unsigned)(buf * BIMG + c * 512) * 2u);
   };
   // j-th slab chunk of this wave for channel chunk cc into slab buffer `buf`
   auto dma_a = [&](int cc, int buf, int j) {
-    const int c = wave + 8 * j;
+    const int c = wave + NWAVE * j;
     if (c >= nslabch) return;
     const int slot = c * 64 + lane, s = slot >> 2, q = (slot & 3) ^ ((s >> 2) & 3);
     long g = m0 - halo + s;
     g = g < 0 ? 0 : (g >= M ? M - 1 : g);                 // out-of-range rows are only ever read masked
     glds16h(x + g * kC + cc * HK + q * 8, sa0 + (unsigned)(buf * (H2_SLABCH * 512) + c * 512) * 2u);
   };
-  const int nb = wave < 4 ? 3 : 2;                         // weight chunks this wave issues per stage
+  const int nb = wave < NCHW - 2 * NWAVE ? 3 : 2;          // weight chunks this wave issues per stage
+  constexpr int JS = (H2_SLABCH + NWAVE - 1) / NWAVE;      // slab chunks per wave, at most
 
   int srow[2];
   unsigned vmask[2];
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
 
   constexpr int NST = HCH * 9;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) dma_a(0, 0, j);
+  for (int j = 0; j < JS; ++j) dma_a(0, 0, j);
 #pragma unroll
   for (int j = 0; j < 3; ++j) dma_w(0, 0, j);
 #pragma unroll
@@ -209,7 +221,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
         const int slot = ks * 2 + rbk;
         __builtin_amdgcn_sched_barrier(0);
         if (slab_now && slot == 0) dma_a(cc + 1, (cc + 1) & 1, 0);
-        if (slab_now && slot == 1) { dma_a(cc + 1, (cc + 1) & 1, 1); dma_a(cc + 1, (cc + 1) & 1, 2); }
+        if (slab_now && slot == 1) {
+#pragma unroll
+          for (int j = 1; j < JS; ++j) dma_a(cc + 1, (cc + 1) & 1, j);
+        }
         if (more && slot == 2) dma_w(st + 2, nbuf, 0);
         if (more && slot == 3) { dma_w(st + 2, nbuf, 1); dma_w(st + 2, nbuf, 2); }
         __builtin_amdgcn_sched_barrier(0);
@@ -240,8 +255,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
   float sc[4], sh[4];
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
-    sc[cb] = scale[wc * 128 + cb * 32 + l31];
-    sh[cb] = shift[wc * 128 + cb * 32 + l31];
+    sc[cb] = scale[n0 + wc * 128 + cb * 32 + l31];
+    sh[cb] = shift[n0 + wc * 128 + cb * 32 + l31];
   }
   if (!out_f32 && !(res && res_f32)) {
     constexpr int TS = 128 + 8;                                  // tile row stride (halves)
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
         for (int i = 0; i < 8; ++i) {                            // 32 rows x 16 pieces of 8 halves
           const int pc = lane + 64 * i, r = pc >> 4, c8 = (pc & 15) * 8;
           const long m = mrow0 + r;
-          const uint4 v = m < M ? *reinterpret_cast<const uint4*>(rh + m * kC + wc * 128 + c8) : make_uint4(0, 0, 0, 0);
+          const uint4 v = m < M ? *reinterpret_cast<const uint4*>(rh + m * kC + n0 + wc * 128 + c8) : make_uint4(0, 0, 0, 0);
           *reinterpret_cast<uint4*>(T + r * TS + c8) = v;
         }
       }
@@ -275,14 +290,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_f16_dma(const _Float16* __restr
       for (int i = 0; i < 8; ++i) {
         const int pc = lane + 64 * i, r = pc >> 4, c8 = (pc & 15) * 8;
         const long m = mrow0 + r;
-        if (m < M) *reinterpret_cast<uint4*>(yh + m * kC + wc * 128 + c8) = *reinterpret_cast<const uint4*>(T + r * TS + c8);
+        if (m < M) *reinterpret_cast<uint4*>(yh + m * kC + n0 + wc * 128 + c8) = *reinterpret_cast<const uint4*>(T + r * TS + c8);
       }
     }
     return;
   }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
-    const int n = wc * 128 + cb * 32 + l31;
+    const int n = n0 + wc * 128 + cb * 32 + l31;
 #pragma unroll
     for (int rbk = 0; rbk < 2; ++rbk) {
 #pragma unroll
@@ -320,11 +335,33 @@ void launch_f32_to_f16(const float* x, uint16_t* y, const int* d_count, int bcap
 void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale, const float* shift, const void* res,
                        int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
   const long rows = (long)bcap * N * N;
-  const int grid = (int)((rows + HM - 1) / HM);
+  const int tiles = (int)((rows + HM - 1) / HM);
   static const int dbg = getenv("AGZ_C16_DEBUG") ? atoi(getenv("AGZ_C16_DEBUG")) : 0;   // timing experiments only
-  auto kern = dbg == 1 ? k_conv3x3_f16_dma<1> : dbg == 2 ? k_conv3x3_f16_dma<2> : dbg == 3 ? k_conv3x3_f16_dma<3> : dbg == 4 ? k_conv3x3_f16_dma<4> : dbg == 5 ? k_conv3x3_f16_dma<5> : k_conv3x3_f16_dma<0>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, (const _Float16*)x, wi, scale, shift, res, res_f32,
-                     y, out_f32, d_count, N, relu);
+  static const int ch = getenv("AGZ_C16_CH") ? atoi(getenv("AGZ_C16_CH")) : 128;
+  const _Float16* xh = (const _Float16*)x;
+#define AGZ_C16_LAUNCH(D, C)                                                                                       \
+  hipLaunchKernelGGL((k_conv3x3_f16_dma<D, C>), dim3(tiles * (kC / C)), dim3(C / 32 * 64), 0, s, xh, wi, scale, shift, \
+                     res, res_f32, y, out_f32, d_count, N, relu)
+  if (ch == 256) {
+    switch (dbg) {
+      case 1: AGZ_C16_LAUNCH(1, 256); break;
+      case 2: AGZ_C16_LAUNCH(2, 256); break;
+      case 3: AGZ_C16_LAUNCH(3, 256); break;
+      case 4: AGZ_C16_LAUNCH(4, 256); break;
+      case 5: AGZ_C16_LAUNCH(5, 256); break;
+      default: AGZ_C16_LAUNCH(0, 256);
+    }
+  } else {
+    switch (dbg) {
+      case 1: AGZ_C16_LAUNCH(1, 128); break;
+      case 2: AGZ_C16_LAUNCH(2, 128); break;
+      case 3: AGZ_C16_LAUNCH(3, 128); break;
+      case 4: AGZ_C16_LAUNCH(4, 128); break;
+      case 5: AGZ_C16_LAUNCH(5, 128); break;
+      default: AGZ_C16_LAUNCH(0, 128);
+    }
+  }
+#undef AGZ_C16_LAUNCH
 }
 
 }  // namespace agz
