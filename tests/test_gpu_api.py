@@ -169,3 +169,16 @@ def test_replay_allgather_over_rccl_from_device_records():
         assert (r["moves"] == w["moves"]).all() and r["result"] == w["result"]
         assert (np.nan_to_num(r["pis"]) == np.nan_to_num(w["pis"])).all()
     eng.close()
+
+
+def test_generation_loop_example():
+    """examples/generation_loop.py: self-play -> replay batches on the device -> arena -> BSON checkpoint"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "generation_loop", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "generation_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    positions, eval_games, same = mod.main(["--board", "5", "--tower", "1", "--games", "6", "--readouts", "16",
+                                            "--batch-size", "8", "--eval-games", "4"])
+    assert positions > 6 and eval_games == 4 and same
