@@ -92,3 +92,28 @@ def allgather_records(engine_or_records, A, group=None, force_collective=False):
         packed = pack_records(engine_or_records, A)
     recs = unpack_records(allgather_packed(packed, group, force_collective=force_collective), A)
     return sorted(recs, key=lambda r: r["game_id"])
+
+
+def broadcast_weights(engine, src=0, group=None):
+    """The optional second collective of SURVEY.md 8e: after a training step on rank `src`, every
+    rank's weight replica is overwritten with that rank's parameters (one flat float32 broadcast --
+    12-24 M parameters, < 100 MB: a single RCCL call).  `engine` needs layers() / get_weights() /
+    set_weights() (alphago.jl_amd.Engine, or NeuralNet.engine)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    keys = list(engine.layers())
+    parts = [np.ascontiguousarray(engine.get_weights(l, k), np.float32).ravel() for l, k in keys]
+    sizes = [p.size for p in parts]
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flat = torch.from_numpy(np.concatenate(parts)).to(device)
+    dist.broadcast(flat, src=src, group=group)
+    if dist.get_rank(group) != src:
+        host = flat.cpu().numpy()
+        off = 0
+        for (l, k), n in zip(keys, sizes):
+            engine.set_weights(l, k, host[off:off + n])
+            off += n
+    return int(flat.numel())

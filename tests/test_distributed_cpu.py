@@ -89,3 +89,49 @@ def test_two_rank_gloo_shard_and_allgather():
     assert [g[0] for g in got[0]] == list(range(games_total))
     single = play(0, 1, games_total, slots=3)    # one rank playing all ids gives the same games
     assert [(r["game_id"], r["num_moves"], r["result"], r["moves"].tolist(), float(np.nansum(r["pis"]))) for r in single] == got[0]
+
+
+class StubWeights:
+    """the three methods broadcast_weights needs, over plain numpy (no GPU in this container)"""
+
+    def __init__(self, seed):
+        rng = np.random.RandomState(seed)
+        self.w = {(l, k): rng.randn(n).astype(np.float32) for (l, k), n in {(0, 0): 3 * 3 * 17 * 8, (0, 1): 8, (-3, 0): 50, (-5, 1): 26}.items()}
+
+    def layers(self):
+        return sorted(self.w)
+
+    def get_weights(self, l, k):
+        return self.w[(l, k)]
+
+    def set_weights(self, l, k, data):
+        assert len(data) == len(self.w[(l, k)])
+        self.w[(l, k)] = np.array(data, np.float32)
+
+
+def bcast_worker(rank, world, port, q):
+    from alphago_jl_amd.distributed import broadcast_weights
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = StubWeights(seed=10 + rank)              # every rank starts with different parameters
+    n = broadcast_weights(net, src=1)
+    q.put((rank, n, {str(k): v.tolist() for k, v in net.w.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_weight_broadcast():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: (n, w) for r, n, w in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = {str(k): v.tolist() for k, v in StubWeights(seed=11).w.items()}      # rank 1's parameters
+    assert got[0][1] == want and got[1][1] == want
+    assert got[0][0] == got[1][0] == sum(len(v) for v in want.values())
