@@ -169,6 +169,10 @@ class NeuralNet:
     def set_weights(self, layer, kind, data):
         self.engine.set_weights(layer, kind, data)
 
+    def set_precision(self, precision="f32"):
+        """tower arithmetic of nn(positions): "f32" (default) or "f16" (fp16 operands, f32 accumulate)"""
+        self.engine.set_precision(precision)
+
     def __call__(self, positions):            # neural_net.jl:57-73
         single = isinstance(positions, Position)
         plist = [positions] if single else list(positions)
@@ -359,13 +363,15 @@ class MCTSPlayer:
 GameRecord = namedtuple("GameRecord", "game_id moves searches_pi qs result result_string was_resign")
 
 
-def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, **cfg):
+def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, precision="f32", **cfg):
     """selfplay(env, nn, num_ro) (src/selfplay.jl:1-45) for `games` concurrent games on the device.
-    Returns one GameRecord per game, ordered by game id."""
+    Returns one GameRecord per game, ordered by game id.  precision="f16" plays with the fp16-operand
+    tower (mixed-precision inference); the default is the exact f32 network."""
     slots = min(games, 1024) if slots is None else slots
     eng = Engine(board_size=env.N, tower_height=nn.tower_height, games=slots, num_readouts=num_ro, seed=seed,
                  record_capacity_games=games + 8, **cfg)
     nn.engine.copy_weights_to(eng)
+    eng.set_precision(precision)
     eng.start(games)
     while eng.records_count() < games:
         eng.step(16)

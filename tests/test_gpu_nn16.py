@@ -90,3 +90,17 @@ def test_precision_argument_is_checked():
     with pytest.raises(ag.AgzError):
         eng._ck(eng.L.agz_net_set_precision(eng.h, 7))
     eng.close()
+
+
+def test_api_precision_switch():
+    env = ag.GoEnv(5)
+    nn = ag.NeuralNet(env, tower_height=2, seed=0)
+    f32 = ag.selfplay(env, nn, 16, games=3, seed=4)
+    f16 = ag.selfplay(env, nn, 16, games=3, seed=4, precision="f16")
+    again = ag.selfplay(env, nn, 16, games=3, seed=4, precision="f16")
+    assert [r.moves for r in f16] == [r.moves for r in again]              # deterministic in either arithmetic
+    assert len(f32) == len(f16) == 3 and all(len(r.moves) > 0 for r in f16)
+    nn.set_precision("f16")
+    pi, v = nn(ag.Position(env))
+    assert abs(pi.sum() - 1) < 1e-5 and -1 <= v <= 1
+    nn.engine.close()
