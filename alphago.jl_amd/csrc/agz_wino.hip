@@ -77,8 +77,10 @@ __device__ __forceinline__ void bt5(float x0, float x1, float x2, float x3, floa
 // covers 16 channels = 4 stages; the transformed values go to an LDS copy of this half-block's part
 // of the four stage images (4 x 13 chunks of 32 rows x 32 B = 1 KB) and leave for HBM as whole
 // 1 KB runs, 16 B per lane -- written straight from registers they were 16-byte fragments spread
-// over four stage images, and the kernel sat at 3.8 TB/s.  Stage images are skewed by {0,4,32,36}
-// dwords in LDS so that the four stage lanes of a tile hit different banks.
+// over four stage images, and the kernel sat at 3.8 TB/s.  Stage images are skewed by {0,4,16,20}
+// dwords in LDS: a ds_write_b64 is served 16 lanes (2 tiles x 8 lanes) at a time over 32 banks, and
+// with that skew the 16 lanes cover all 32 banks exactly once (PMC: SQ_LDS_BANK_CONFLICT 0; the
+// {0,4,32,36} skew that would suit a 64-bank / 32-lane model measured 40 % conflicted cycles).
 template <int TPB, bool NT>   // tiles per workgroup: 32 (8 lanes = 64 B per patch point) or 16 (16 lanes = one 128 B line)
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T) {
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
   constexpr int IMG = 13 * CH + 64;          // LDS stride between the stage images of a pass
   constexpr int CPR = 256 / (TPB * 2);       // chunks copied out per round
   __shared__ __attribute__((aligned(16))) float img[SP * IMG];
-  auto skew = [](int sl) { return TPB == 32 ? (sl & 1) * 4 + (sl >> 1) * 32 : (sl & 1) * 4 + (sl >> 1) * 16; };
+  auto skew = [](int sl) { return (sl & 1) * 4 + (sl >> 1) * 16; };
   const int P = N * N, TT = T * T;
   const long Mt = (long)(*d_count) * TT;
   constexpr int PARTS = WT / TPB;
