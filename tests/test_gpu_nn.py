@@ -93,3 +93,25 @@ def test_weight_shape_errors():
     assert eng.param_count(0, 0) == 3 * 3 * 17 * 256
     assert eng.param_count(ag._lib.L_POLICY_FC, 0) == 162 * 82
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_full_batch_is_deterministic_and_matches_small_batches(precision):
+    """race screen at the bench's batch size (8192 positions, every CU busy, DMA rings full): repeated
+    forwards are bit-identical, and so is a slice evaluated as a small batch"""
+    N, tower, B = 9, 4, 8192
+    rng = np.random.RandomState(1)
+    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    eng.init_synthetic(2)
+    eng.set_precision(precision)
+    feats = (rng.rand(B, 17 * N * N) < 0.25).astype(np.float32)
+    feats[:, 16 * N * N:] = np.where(rng.rand(B, 1) < 0.5, 1.0, -1.0)
+    pi0, v0 = eng.forward_features(feats)
+    for _ in range(6):
+        pi, v = eng.forward_features(feats)
+        assert (pi == pi0).all() and (v == v0).all()
+    for lo in (0, 3000, B - 300):
+        spi, sv = eng.forward_features(feats[lo:lo + 300])
+        assert (spi == pi0[lo:lo + 300]).all() and (sv == v0[lo:lo + 300]).all(), lo
+    assert np.isfinite(pi0).all() and np.allclose(pi0.sum(1), 1, atol=1e-5)
+    eng.close()
