@@ -13,8 +13,8 @@
 //
 //   tower activations  [M][256] half in HBM (the f32 stem output is converted once per forward; the
 //                      last conv writes f32 for the heads; residuals in either type)
-//   workgroup          512 threads = 8 waves = 4 row groups (64 rows) x 2 cout halves (128);
-//                      a wave holds 2 x 4 accumulator tiles of 32x32 (128 VGPRs)
+//   workgroup          256 rows x CH couts; CH = 128 in the product: 4 waves (one per 64-row group), two
+//                      workgroups per CU; a wave holds 2 x 4 accumulator tiles of 32x32 (128 VGPRs)
 //   weights            stored in HBM as ready-made padded LDS tile images Wi[stage 72][256 rows][40 halves]
 //                      (80 B rows: the 16 rows of a ds_read_b128 phase fall on 16 distinct 16-B bank
 //                      groups), true-convolution flip applied at pack time; brought in by LDS-DMA
@@ -28,8 +28,9 @@
 //                      front, the DMA instructions interleaved between the MFMAs (see agz_wino.hip for
 //                      why), one barrier per stage
 //   epilogue           half-in/half-out layers stage their tile through LDS so that residual and result
-//                      move as 16-byte pieces of whole rows (2-byte scatters cost 0.27 ms per layer)  A first version that moved the
-//                      weights global -> VGPR -> LDS topped out at ~10 B/clk/CU on that stream (1.19 ms).
+//                      move as 16-byte pieces of whole rows (2-byte scatters cost 0.27 ms per layer)
+//   history            a first version that moved the weights global -> VGPR -> LDS topped out at
+//                      ~10 B/clk/CU on that stream (1.19 ms per layer; now 0.80)
 // The reduction order of an output is fixed (chunk, tap, k) and does not depend on where its row
 // sits in the batch: tree parity with the oracle (which calls this network) stays bit-exact.
 #include "agz_nn.h"
