@@ -41,7 +41,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "steps", "positions", "games_started", "games_finished", "evals", "duplicate_evals",
-        "terminal_visits", "root_visits", "nodes_in_use", "pool_exhausted", "resigned_games", "live_games")]
+        "terminal_visits", "root_visits", "nodes_in_use", "pool_exhausted", "resigned_games", "live_games",
+        "records_dropped")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -189,11 +189,14 @@ class NeuralNet:
         return self.engine.forward_features(feats)
 
 
-def load_model(model_dir, env):
+def load_model(model_dir, env, bn_field="auto"):
     """load_model(str, env), src/play.jl:3-21: BSON parameter lists (and BatchNorm statistics when the
-    struct dumps are present) -> NeuralNet; the tower height is read off the base parameter list"""
+    struct dumps are present) -> NeuralNet; the tower height is read off the base parameter list.
+    bn_field says what the 5th field of a dumped Flux.BatchNorm is: "std" (Flux <= 0.7, the files the
+    reference ships: forward (x - mu) / sigma), "var" (Flux >= 0.8: sigma^2, eps under the root) or
+    "auto" (decide per layer from the dump: Float64 eps = 1e-8 / TrackedArray parameters => "std")."""
     from . import bson_weights as bw
-    ck = bw.read_checkpoint(model_dir)
+    ck = bw.read_checkpoint(model_dir, bn_field)
     nn = NeuralNet(env, tower_height=bw.tower_height_of(ck["base"]))
     bw.apply_param_lists(nn.engine, ck["base"], ck["value"], ck["policy"], ck.get("base_stats"),
                          ck.get("value_stats"), ck.get("policy_stats"))
@@ -290,8 +293,14 @@ class MCTSPlayer:
     def initialize_game(self, pos=None):      # mcts_play.jl:110-118
         pos = Position(self.env) if pos is None else pos
         last = -1 if not pos.recent else to_flat(pos.recent[-1].move, self.env)
+        # initialize_game!(player, pos) keeps pos.board_deltas (board.jl:505-506): the up-to-7 older boards the
+        # history planes need are B_{k+1} = B_k - delta_k (features.jl:8-14), newest first
+        hist, b = [], pos._flat()[0].astype(np.int16)
+        for k in range(min(7, pos.board_deltas.shape[0])):
+            b = b - np.ascontiguousarray(pos.board_deltas[k].T).reshape(-1)
+            hist.append(b.astype(np.int8))
         self.engine.tree_init(0, pos._flat()[0], n=pos.n, to_play=pos.to_play, ko=pos._ko0(), caps=pos.caps,
-                              last_move=last, komi=pos.komi)
+                              last_move=last, komi=pos.komi, history=np.stack(hist) if hist else None)
         self.engine.set_draw(0, self._game_id, 0)
         self.qs, self.searches_pi = [], []
         self.result, self.result_string = 0, ""
@@ -375,6 +384,9 @@ def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, precision="f32", 
     eng.start(games)
     while eng.records_count() < games:
         eng.step(16)
+        if eng.stats()["pool_exhausted"]:
+            eng.close()
+            raise _lib.AgzError(_lib.POOL_EXHAUSTED, "node pool exhausted; raise max_nodes_per_game")
     out = []
     for r in eng.records():
         if r["was_resign"]:
@@ -414,6 +426,9 @@ def evaluate(env, black_net, white_net, num_games=400, ro=800, verbose=False, se
     eng.start(num_games)
     while eng.records_count() < num_games:
         eng.step(16)
+        if eng.stats()["pool_exhausted"]:
+            eng.close()
+            raise _lib.AgzError(_lib.POOL_EXHAUSTED, "node pool exhausted; raise max_nodes_per_game")
     recs = eng.records()
     st = eng.stats()
     eng.close()

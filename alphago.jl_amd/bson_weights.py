@@ -168,10 +168,33 @@ def write_param_list(path, key, arrays):
         f.write(dumps({key: [encode_array(a) for a in arrays]}))
 
 
-def read_batchnorm_stats(path):
-    """walk a `@save`d model struct dump and return [(mu, sigma2, eps), ...] for every
-    Flux.BatchNorm in depth-first (= layer) order.  BatchNorm fields (Flux 0.6-0.10):
-    lambda, beta, gamma, mu, sigma2, eps, momentum, active."""
+def _is_tracked(x):
+    t = x.get("type") if isinstance(x, dict) else None
+    return isinstance(t, dict) and t.get("name") == ["Flux", "Tracker", "TrackedArray"]
+
+
+def batchnorm_stat_field(d):
+    """which statistic the 5th field of a dumped Flux.BatchNorm holds.
+
+    Flux <= 0.7 (Tracker era): struct (lambda, beta, gamma, mu, sigma, eps, momentum, active) with
+    eps::Float64 = 1e-8 and TrackedArray parameters; test mode computes (x - mu) ./ sigma -- the field is
+    the moving STANDARD DEVIATION with eps already folded in.  Flux >= 0.8: (..., mu, sigma2, eps::Float32 =
+    1f-5, momentum, ...) and the forward divides by sqrt(sigma2 + eps) -- the field is the VARIANCE.
+    The files shipped with the reference (models/agz_*.bson) are of the first kind."""
+    tracked = _is_tracked(d[1]) or _is_tracked(d[2])
+    eps = d[5]
+    old_eps = isinstance(eps, float) and abs(eps - 1e-8) < 1e-12
+    return "std" if (tracked or old_eps) else "var"
+
+
+def read_batchnorm_stats(path, bn_field="auto"):
+    """walk a `@save`d model struct dump and return [(mu, sigma2, eps), ...] for every Flux.BatchNorm in
+    depth-first (= layer) order, ALWAYS as (mean, variance, eps) such that the inference affine is
+    gamma / sqrt(sigma2 + eps).  bn_field: "auto" (detect the Flux generation per layer, see
+    batchnorm_stat_field), "std" (field 5 is sigma: returns sigma^2 and eps = 0, i.e. exactly
+    (x - mu) / sigma) or "var" (field 5 is sigma^2, eps kept)."""
+    if bn_field not in ("auto", "std", "var"):
+        raise ValueError('bn_field must be "auto", "std" or "var"')
     doc = loads(open(path, "rb").read())
     out = []
 
@@ -180,7 +203,12 @@ def read_batchnorm_stats(path):
             t = x.get("type")
             if x.get("tag") == "struct" and isinstance(t, dict) and t.get("name") == ["Flux", "BatchNorm"]:
                 d = x["data"]
-                out.append((decode_array(d[3]).ravel(), decode_array(d[4]).ravel(), float(d[5])))
+                mu, field, eps = decode_array(d[3]).ravel(), decode_array(d[4]).ravel(), float(d[5])
+                kind = batchnorm_stat_field(d) if bn_field == "auto" else bn_field
+                if kind == "std":
+                    out.append((mu, (field.astype(np.float64) ** 2).astype(np.float32), 0.0))
+                else:
+                    out.append((mu, field, eps))
                 return
             for v in x.values():
                 walk(v)
@@ -281,22 +309,26 @@ def extract_param_lists(engine):
     return dict(base=base, value=value, policy=policy, base_stats=base_stats, value_stats=[vs], policy_stats=[ps])
 
 
-def read_checkpoint(model_dir):
-    """`load_model(str, env)` (src/play.jl:3-21): str/weights/agz_*.bson (+ BatchNorm statistics from
-    str/agz_*.bson when those struct dumps exist)"""
+def read_checkpoint(model_dir, bn_field="auto"):
+    """`load_model(str, env)` (src/play.jl:3-21): str/weights/agz_*.bson + BatchNorm statistics.  The
+    statistics come from the side files weights/agz_*_bnstats.bson when write_checkpoint has put them
+    there (they belong to exactly these weights), else from the reference-style struct dumps
+    str/agz_*.bson (bn_field: how their 5th BatchNorm field is read, see read_batchnorm_stats)."""
     w = os.path.join(model_dir, "weights")
     out = dict(base=read_param_list(os.path.join(w, "agz_base.bson")),
                value=read_param_list(os.path.join(w, "agz_value.bson")),
                policy=read_param_list(os.path.join(w, "agz_policy.bson")))
     for part in ("base", "value", "policy"):
-        p = os.path.join(model_dir, f"agz_{part}.bson")
-        if os.path.exists(p):
-            out[part + "_stats"] = read_batchnorm_stats(p)
-        else:
-            p = os.path.join(w, f"agz_{part}_bnstats.bson")      # written by write_checkpoint
-            out[part + "_stats"] = None if not os.path.exists(p) else [
+        side = os.path.join(w, f"agz_{part}_bnstats.bson")
+        dump = os.path.join(model_dir, f"agz_{part}.bson")
+        if os.path.exists(side):
+            out[part + "_stats"] = [
                 (decode_array(d["mu"]).ravel(), decode_array(d["sigma2"]).ravel(), float(d["eps"]))
-                for d in loads(open(p, "rb").read())["stats"]]
+                for d in loads(open(side, "rb").read())["stats"]]
+        elif os.path.exists(dump):
+            out[part + "_stats"] = read_batchnorm_stats(dump, bn_field)
+        else:
+            out[part + "_stats"] = None
     return out
 
 

@@ -368,7 +368,7 @@ void Engine::net_select(int which) {
 void Engine::start(int64_t total_games) {
   V_.total_games = total_games;
   AGZ_HIP(hipMemsetAsync(V_.counters, 0, sizeof(unsigned long long) * CT_COUNT, stream_));
-  AGZ_HIP(hipMemsetAsync(V_.ar_hdr, 0, sizeof(int32_t) * 4 * (V_.games / 2 + 1), stream_));
+  AGZ_HIP(hipMemsetAsync(V_.ar_hdr, 0, sizeof(int32_t) * 5 * (V_.games / 2 + 1), stream_));
   std::vector<GameState> gs(V_.games);
   std::memset(gs.data(), 0, sizeof(GameState) * gs.size());
   for (auto& g : gs) g.phase = G_IDLE;
@@ -460,6 +460,7 @@ void Engine::stats(agz_stats* out) {
   out->pool_exhausted = (int64_t)c[CT_POOL_EXHAUSTED];
   out->resigned_games = (int64_t)c[CT_RESIGNED];
   out->root_visits = (int64_t)c[CT_ROOTVISITS];
+  out->records_dropped = c[CT_RECORDED] > (unsigned long long)V_.fin_cap ? (int64_t)(c[CT_RECORDED] - V_.fin_cap) : 0;
   for (const auto& g : gs) {
     out->nodes_in_use += g.nodes_used;
     out->live_games += (g.phase != G_RETIRED && g.phase != G_IDLE);
@@ -470,7 +471,7 @@ void Engine::stats(agz_stats* out) {
 
 int64_t Engine::records_count() {
   unsigned long long f = 0;
-  AGZ_HIP(hipMemcpyAsync(&f, V_.counters + CT_FINISHED, sizeof(f), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(&f, V_.counters + CT_RECORDED, sizeof(f), hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
   return (int64_t)std::min<unsigned long long>(f, (unsigned long long)V_.fin_cap);
 }
@@ -535,7 +536,7 @@ void Engine::records_export_packed(void* dst, int64_t capacity, bool is_device) 
 }
 
 void Engine::records_clear() {
-  AGZ_HIP(hipMemsetAsync(V_.counters + CT_FINISHED, 0, sizeof(unsigned long long), stream_));
+  AGZ_HIP(hipMemsetAsync(V_.counters + CT_RECORDED, 0, sizeof(unsigned long long), stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
 }
 

@@ -70,7 +70,7 @@ inline void for_each_buffer(View& V, F&& f) {
   f(V.fin_q, (size_t)V.fin_cap * mgl);
   f(V.counters, (size_t)CT_COUNT);
   f(V.batch_count, (size_t)2);
-  f(V.ar_hdr, (size_t)4 * (V.games / 2 + 1));
+  f(V.ar_hdr, (size_t)5 * (V.games / 2 + 1));        // 4 header words + 1 abort word per pair (agz_search.h)
 }
 
 }  // namespace agz

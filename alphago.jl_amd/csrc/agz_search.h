@@ -773,7 +773,8 @@ template <class W>
 AGZ_FN void game_finish(W& w, const View& V, Scratch& S, int g, int winner, int was_resign, float score) {
   GameState& G = V.gs[g];
   const int nm = G.move_count;
-  const long slot = (long)(w.fetch_add(&V.counters[CT_FINISHED], 1ull) % (unsigned long long)V.fin_cap);
+  const long slot = (long)(w.fetch_add(&V.counters[CT_RECORDED], 1ull) % (unsigned long long)V.fin_cap);
+  w.count(&V.counters[CT_FINISHED], 1);
   const int mgl = V.max_game_length;
   if (w.leader()) {
     agz_game_header h;
@@ -898,6 +899,11 @@ AGZ_FN void game_select_phase(W& w, const View& V, Scratch& S, int g, int par) {
 // move on its tree and takes over.  Writer and reader therefore always run in different kernel
 // launches: no intra-kernel communication, deterministic.
 
+// arena mailbox words of a slot pair: ar_hdr[4 * pair .. +3] = {local game index, plies played, done, result};
+// after the (games/2 + 1) headers, one abort word per pair = 1 + local game index of a game one side had to drop
+constexpr int kArenaWordsPerPair = 5;
+AGZ_FN int32_t* arena_abort_word(const View& V, int pair) { return V.ar_hdr + 4 * (V.games / 2 + 1) + pair; }
+
 template <class W>
 AGZ_FN void arena_finish(W& w, const View& V, Scratch& S, int g, bool emit, int winner, int was_resign) {
   GameState& G = V.gs[g];
@@ -979,7 +985,15 @@ AGZ_FN void arena_pre(W& w, const View& V, Scratch& S, int g) {
       const long pg = (long)(g ^ 1) * V.max_game_length + G.move_count;
       const int a = V.rec_moves[pg];
       const float q = V.rec_q[pg];
-      if (!arena_apply(w, V, S, g, a, q)) { arena_finish(w, V, S, g, false, 0, 0); return; }
+      if (!arena_apply(w, V, S, g, a, q)) {
+        // node pool exhausted while following the partner's move: the partner is parked in G_ARENA_WAIT for
+        // this slot's reply and would wait forever.  Raise the pair's abort word; the partner reads it in
+        // k_post (a different launch, so still no intra-kernel communication) and files the game as void.
+        if (w.leader()) arena_abort_word(V, pair)[0] = G.arena_k + 1;
+        w.sync();
+        arena_finish(w, V, S, g, false, 0, 0);
+        return;
+      }
     } else if (!hdone) {
       return;
     }
@@ -1077,6 +1091,10 @@ template <class W>
 AGZ_FN void game_post(W& w, const View& V, Scratch& S, int g) {
   GameState& G = V.gs[g];
   const int nl = G.nleaves;
+  if (V.arena && G.phase == G_ARENA_WAIT) {                 // the partner dropped this game in k_pre (pool exhausted)
+    if (arena_abort_word(V, g >> 1)[0] == G.arena_k + 1) arena_finish(w, V, S, g, true, 0, 0);
+    return;
+  }
   if (V.arena && G.phase == G_SEARCH && nl <= 0) {          // a select phase of terminal leaves only
     if (!(G.rootN < G.target)) arena_move_phase(w, V, S, g);
     return;

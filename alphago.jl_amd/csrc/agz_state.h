@@ -66,7 +66,9 @@ struct GameState {
 
 enum Counter : int {
   CT_STEPS = 0, CT_POSITIONS, CT_STARTED, CT_FINISHED, CT_EVALS, CT_DUP, CT_TERMINAL, CT_ROOTVISITS,
-  CT_POOL_EXHAUSTED, CT_RESIGNED, CT_CLAIMED, CT_COUNT
+  CT_POOL_EXHAUSTED, CT_RESIGNED, CT_CLAIMED,
+  CT_RECORDED,     // records written to the finished-game ring since the last records_clear (CT_FINISHED never resets)
+  CT_COUNT
 };
 
 struct View {

@@ -30,6 +30,7 @@ struct IllegalMove <: Exception end          # src/AlphaGo.jl:8
 # ---- status codes (include/agz.h)
 const AGZ_OK, AGZ_ILLEGAL_MOVE, AGZ_ASSERT_DONE_NODE, AGZ_HISTORY_INCOMPLETE, AGZ_BAD_SHAPE,
       AGZ_ASSERT_SOFTPICK = 0, 1, 2, 3, 4, 5
+const AGZ_BAD_ARGUMENT, AGZ_HIP_ERROR, AGZ_POOL_EXHAUSTED, AGZ_RCCL_ERROR, AGZ_NOT_READY = 6, 7, 8, 9, 10
 
 # agz_config: field order and types must match include/agz.h exactly (112 bytes)
 struct AgzConfig
@@ -59,6 +60,12 @@ struct AgzGameHeader
   final_score::Float32; reserved::Int32
 end
 
+struct AgzStats            # agz_stats, include/agz.h: thirteen Int64 counters
+  steps::Int64; positions::Int64; games_started::Int64; games_finished::Int64; evals::Int64
+  duplicate_evals::Int64; terminal_visits::Int64; root_visits::Int64; nodes_in_use::Int64
+  pool_exhausted::Int64; resigned_games::Int64; live_games::Int64; records_dropped::Int64
+end
+
 mutable struct Engine
   handle::Ptr{Cvoid}
   cfg::AgzConfig
@@ -72,6 +79,15 @@ function check(e::Engine, st::Integer)
     throw(AssertionError(msg))                                          # mcts.jl:190,196 ...
   error("libagz status $st: $msg")
 end
+
+function stats(e::Engine)
+  st = Ref{AgzStats}()
+  check(e, ccall((:agz_engine_stats, libagz), Int32, (Ptr{Cvoid}, Ref{AgzStats}), e.handle, st))
+  st[]
+end
+
+check_pool(e::Engine) = stats(e).pool_exhausted > 0 &&
+  error("libagz: node pool exhausted (status $AGZ_POOL_EXHAUSTED); raise max_nodes_per_game")
 
 function Engine(; board_size = 19, tower_height = 19, games = 1, num_readouts = 800,
                 parallel_readouts = 8, two_player_mode = false, komi = 7.5, c_puct = 0.96,
@@ -255,10 +271,20 @@ end
 function initialize_game!(p::MCTSPlayer, pos = nothing)                        # mcts_play.jl:110-118
   pos === nothing && (pos = Position(p.env))
   last = isempty(pos.recent) ? -1 : to_flat(pos.recent[end].move, p.env) - 1
-  info = AgzPositionInfo(pos.n, pos.to_play, ko0(pos), pos.caps[1], pos.caps[2], last, -1, 0, pos.komi)
+  # the reference keeps pos.board_deltas (board.jl:505-506); the engine wants the older boards themselves,
+  # newest first: B_{k+1} = B_k - delta_k (features.jl:8-14)
+  k = min(7, size(pos.board_deltas, 3))
+  hist = Matrix{Int8}(undef, length(pos.board), k)
+  b = copy(pos.board)
+  for i in 1:k
+    b = b .- pos.board_deltas[:, :, i]
+    hist[:, i] = vec(b)
+  end
+  prev = length(pos.recent) < 2 ? -1 : to_flat(pos.recent[end-1].move, p.env) - 1
+  info = AgzPositionInfo(pos.n, pos.to_play, ko0(pos), pos.caps[1], pos.caps[2], last, prev, k, pos.komi)
   check(p.engine, ccall((:agz_tree_init, libagz), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Int8}, Ref{AgzPositionInfo}, Ptr{Int8}),
-        p.engine.handle, 0, pos.board, info, C_NULL))
+        p.engine.handle, 0, pos.board, info, k == 0 ? C_NULL : hist))      # ccall roots `hist` for the call
   p.result = 0; p.qs = Float32[]; p.searches_π = Vector{Float32}[]
   p
 end
@@ -374,6 +400,7 @@ function selfplay(env::GoEnv, nn::NeuralNet, num_ro::Int = 800; games::Int = 1, 
   check(e, ccall((:agz_selfplay_start, libagz), Int32, (Ptr{Cvoid}, Int64), e.handle, games))
   while ccall((:agz_records_count, libagz), Int64, (Ptr{Cvoid},), e.handle) < games
     check(e, ccall((:agz_selfplay_step, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, 16))
+    check_pool(e)     # a game whose node pool ran out cannot finish: raise instead of stepping for ever
   end
   recs = GameRecord[]
   A = env.action_space
@@ -451,6 +478,7 @@ function evaluate(env::GoEnv, black_net::NeuralNet, white_net::NeuralNet; num_ga
   check(e, ccall((:agz_selfplay_start, libagz), Int32, (Ptr{Cvoid}, Int64), e.handle, num_games))
   while ccall((:agz_records_count, libagz), Int64, (Ptr{Cvoid},), e.handle) < num_games
     check(e, ccall((:agz_selfplay_step, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, 16))
+    check_pool(e)
   end
   games_won = 0
   for k in 0:num_games-1

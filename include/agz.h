@@ -182,6 +182,8 @@ typedef struct {
   int64_t pool_exhausted;      /* >0 => results invalid, raise max_nodes_per_game       */
   int64_t resigned_games;
   int64_t live_games;
+  int64_t records_dropped;     /* finished games overwritten in the record ring since the last
+                                * agz_records_clear (ring = record_capacity_games): drain more often */
 } agz_stats;
 agz_status agz_engine_stats(agz_engine* e, agz_stats* out);            /* synchronises */
 /* external-network mode (MCTSPlayer.network duck typing, mcts_play.jl:5,89): after a step's

@@ -127,7 +127,9 @@ class OracleNetSink:
 
 def shipped(model_dir="/root/reference/models"):
     """the 9x9 / tower-0 network shipped with the reference (models/weights/agz_*.bson, BatchNorm
-    statistics and eps = 1e-8 from models/agz_*.bson), decoded by alphago.jl_amd.bson_weights:
+    statistics from the Flux <= 0.7 struct dumps models/agz_*.bson, whose 5th BatchNorm field is the moving
+    STANDARD DEVIATION -- stored here as variance = sigma^2 with eps = 0, plus the raw field and eps
+    as `*_field_*` / `*_fieldeps_*`), decoded by alphago.jl_amd.bson_weights:
     its parameters (data, 76 k floats) + float64 oracle outputs on seeded positions.  Exercises what
     synthetic weights cannot: non-identity BatchNorm folding, non-zero biases, Flux kernel flip."""
     import alphago_jl_amd as ag
@@ -145,8 +147,10 @@ def shipped(model_dir="/root/reference/models"):
     for part in ("base", "value", "policy"):
         for i, a in enumerate(ck[part]):
             out[f"{part}_{i}"] = a
+        raw = bw.read_batchnorm_stats(os.path.join(model_dir, f"agz_{part}.bson"), "var")
         for i, (m, v, e) in enumerate(ck[part + "_stats"]):
             out[f"{part}_mu_{i}"], out[f"{part}_var_{i}"], out[f"{part}_eps_{i}"] = m, v, np.array([e])
+            out[f"{part}_field_{i}"], out[f"{part}_fieldeps_{i}"] = raw[i][1], np.array([raw[i][2]])
     np.savez_compressed(os.path.join(HERE, "shipped_9x9_t0.npz"), **out)
 
 

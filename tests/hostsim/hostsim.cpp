@@ -102,7 +102,7 @@ void hs_start(void* h, int64_t total_games) {
   Sim* s = (Sim*)h;
   s->V.total_games = total_games;
   memset(s->V.counters, 0, sizeof(unsigned long long) * agz::CT_COUNT);
-  memset(s->V.ar_hdr, 0, sizeof(int32_t) * 4 * (s->V.games / 2 + 1));
+  memset(s->V.ar_hdr, 0, sizeof(int32_t) * 5 * (s->V.games / 2 + 1));
   for (int g = 0; g < s->V.games; ++g) {
     memset(&s->V.gs[g], 0, sizeof(agz::GameState));
     s->V.gs[g].phase = agz::G_IDLE;
@@ -173,7 +173,7 @@ int hs_live_games(void* h) {
 
 long hs_records_count(void* h) {
   Sim* s = (Sim*)h;
-  const unsigned long long f = s->V.counters[agz::CT_FINISHED];
+  const unsigned long long f = s->V.counters[agz::CT_RECORDED];
   return (long)(f < (unsigned long long)s->V.fin_cap ? f : s->V.fin_cap);
 }
 void hs_record_header(void* h, long k, agz_game_header* out) { *out = ((Sim*)h)->V.fin_hdr[k]; }

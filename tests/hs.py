@@ -8,7 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CT = ["steps", "positions", "started", "finished", "evals", "dup", "terminal", "rootvisits",
-      "pool_exhausted", "resigned", "claimed"]
+      "pool_exhausted", "resigned", "claimed", "recorded"]
 
 
 class AgzConfig(C.Structure):

@@ -73,7 +73,69 @@ def test_checkpoint_roundtrip_with_bn_stats():
         for part in ("base", "value", "policy"):
             assert all((x == y).all() for x, y in zip(ck[part], lists[part]))
             (m, v, e), (m2, v2, e2) = ck[part + "_stats"][0], lists[part + "_stats"][0]
-            assert (m == m2).all() and (v == v2).all() and e == pytest.approx(1e-8)
+            assert (m == m2).all() and (v == v2).all() and e == e2 == 0.0
+        # save -> load is a round trip even when stale reference-style struct dumps sit in the directory:
+        # the side files written with the weights win
+        for part in ("base", "value", "policy"):
+            with open(os.path.join(d, f"agz_{part}.bson"), "wb") as f:
+                f.write(bw.dumps({"x": _bn_dump(np.ones(1), np.full(1, 9.0), 1e-8, old=True)}))
+        ck = bw.read_checkpoint(d)
+        assert all((ck[p + "_stats"][0][1] == lists[p + "_stats"][0][1]).all() for p in ("base", "value", "policy"))
+
+
+def _bn_dump(mu, field, eps, old):
+    """a dumped Flux.BatchNorm struct in the two generations (field order of both: lambda, beta, gamma, mu,
+    sigma | sigma2, eps, momentum, active)"""
+    arr = lambda a: bw.encode_array(np.asarray(a, np.float32))
+    par = (lambda a: {"tag": "struct", "type": {"tag": "datatype", "name": ["Flux", "Tracker", "TrackedArray"], "params": []},
+                      "data": [arr(a)]}) if old else arr
+    return {"tag": "struct", "type": {"tag": "datatype", "name": ["Flux", "BatchNorm"], "params": []},
+            "data": [{"tag": "struct", "type": {"tag": "datatype", "name": ["NNlib", "#relu"], "params": []}, "data": []},
+                     par(np.zeros_like(mu)), par(np.ones_like(mu)), arr(mu), arr(field), eps, 0.1, True]}
+
+
+def test_batchnorm_field_generation_is_detected_and_switchable():
+    """Flux <= 0.7 dumps (TrackedArray parameters, Float64 eps = 1e-8) carry sigma; Flux >= 0.8 carry sigma^2.
+    read_batchnorm_stats always returns (mean, variance, eps) for gamma / sqrt(variance + eps)."""
+    mu, field = np.array([0.5, -1.0], np.float32), np.array([0.25, 2.0], np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        po, pn = os.path.join(d, "old.bson"), os.path.join(d, "new.bson")
+        open(po, "wb").write(bw.dumps({"bn": {"layers": [_bn_dump(mu, field, 1e-8, old=True)]}}))
+        open(pn, "wb").write(bw.dumps({"bn": {"layers": [_bn_dump(mu, field, float(np.float32(1e-5)), old=False)]}}))
+        (m, v, e), = bw.read_batchnorm_stats(po)                    # auto -> std
+        assert (m == mu).all() and np.allclose(v, field ** 2, rtol=1e-7) and e == 0.0
+        (m, v, e), = bw.read_batchnorm_stats(pn)                    # auto -> var
+        assert (v == field).all() and e == pytest.approx(1e-5)
+        (m, v, e), = bw.read_batchnorm_stats(po, "var")             # explicit override, both ways
+        assert (v == field).all() and e == 1e-8
+        (m, v, e), = bw.read_batchnorm_stats(pn, "std")
+        assert np.allclose(v, field ** 2, rtol=1e-7) and e == 0.0
+        with pytest.raises(ValueError):
+            bw.read_batchnorm_stats(po, "sigma")
+
+
+def test_shipped_stem_activations_have_unit_scale_under_the_std_reading():
+    """the check that tells sigma from sigma^2 without Flux: a trained BatchNorm normalises its input, so on
+    real positions the stem's pre-affine activations (conv(x) + b - mu) / sigma must have per-channel spread of
+    order 1.  Read as a variance, the same field gives spreads of sqrt(sigma) ~ 0.2-0.9."""
+    import torch
+    from test_hostsim_go import random_positions
+    d, lists = fixture_lists()
+    W, b = lists["base"][0], lists["base"][1]                     # [3,3,17,256] Flux layout, true convolution
+    positions = random_positions(9, 24, 60, seed=5)
+    x = np.stack([orc.feats(p).reshape(17, 9, 9) for p in positions]).astype(np.float64)    # [B,17,col,row] col-major
+    w = torch.from_numpy(np.ascontiguousarray(W[::-1, ::-1].transpose(3, 2, 1, 0)).astype(np.float64))
+    y = torch.nn.functional.conv2d(torch.from_numpy(x), w, padding=1).numpy() + b.reshape(1, -1, 1, 1)
+    mu, sigma = d["base_mu_0"].astype(np.float64), d["base_field_0"].astype(np.float64)
+    spread = y.transpose(1, 0, 2, 3).reshape(256, -1).std(1)
+    live = spread > 1e-3
+    ratio_std = np.median(spread[live] / sigma[live])
+    ratio_var = np.median(spread[live] / np.sqrt(sigma[live] + 1e-8))
+    print(f"median activation spread / sigma = {ratio_std:.3f}; / sqrt(field) = {ratio_var:.3f}")
+    assert 0.6 < ratio_std < 1.4
+    assert abs(np.log(ratio_std)) < abs(np.log(ratio_var))
+    centred = np.abs(y.transpose(1, 0, 2, 3).reshape(256, -1).mean(1) - mu)[live] / sigma[live]
+    assert np.median(centred) < 0.5
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="reference checkout not present")
@@ -82,8 +144,11 @@ def test_shipped_files_decode_and_rewrite_byte_exact():
     d, lists = fixture_lists()
     for part in ("base", "value", "policy"):
         assert all((x == y).all() and x.shape == y.shape for x, y in zip(ck[part], lists[part]))
-        m, v, e = ck[part + "_stats"][0]
-        assert (m == lists[part + "_stats"][0][0]).all() and (v == lists[part + "_stats"][0][1]).all() and e == 1e-8
+        m, v, e = ck[part + "_stats"][0]                       # Flux <= 0.7 dump: field 5 is sigma -> (sigma^2, 0)
+        assert (m == lists[part + "_stats"][0][0]).all() and (v == lists[part + "_stats"][0][1]).all() and e == 0.0
+        raw = bw.read_batchnorm_stats(os.path.join(REF_MODELS, f"agz_{part}.bson"), "var")[0]
+        assert (raw[1] == d[f"{part}_field_0"]).all() and raw[2] == 1e-8
+        assert np.allclose(v, raw[1].astype(np.float64) ** 2, rtol=1e-6)
     with tempfile.TemporaryDirectory() as t:
         bw.write_checkpoint(t, ck)
         for part in ("base", "value", "policy"):

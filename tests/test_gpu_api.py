@@ -182,3 +182,35 @@ def test_generation_loop_example():
     positions, eval_games, same = mod.main(["--board", "5", "--tower", "1", "--games", "6", "--readouts", "16",
                                             "--batch-size", "8", "--eval-games", "4"])
     assert positions > 6 and eval_games == 4 and same
+
+
+def test_initialize_game_from_a_midgame_position_keeps_its_history():
+    """initialize_game!(player, pos) keeps pos.board_deltas (board.jl:505-506, mcts_play.jl:110-118): the history
+    planes of the first leaves after starting from a mid-game position equal get_feats of the positions the
+    reference would build (the history was dropped and the oldest board repeated instead)."""
+    env = GoEnv(N)
+    pos = Position(env)
+    for c in [(2, 2), (6, 6), (2, 6), (6, 2), (4, 4), (3, 3), (5, 5), (1, 1), (7, 7)]:
+        pos = pos.play_move(c)
+    assert pos.board_deltas.shape[0] == 7
+    seen = []
+
+    class Spy(DummyNet):
+        def __call__(self, leaves):
+            seen.extend(np.asarray(l.feats, np.float32).copy() for l in leaves)
+            return super().__call__(leaves)
+
+    player = MCTSPlayer(env, Spy(env))
+    player.initialize_game(pos)
+    player.tree_search(1)                        # the root itself is the first leaf
+    player.tree_search(2)                        # then two children
+    want_root = ag.get_feats(pos).transpose(0, 2, 1).reshape(-1)      # [plane, row, col] -> plane-major, p = row + N*col
+    assert (seen[0] == want_root).all()
+    assert len(seen) >= 2
+    # every child leaf: features of pos.play_move(its move); identify the move by the one extra stone of plane pair 1
+    legal = pos.all_legal_moves()
+    for f in seen[1:]:
+        cands = [a for a in range(N * N) if legal[a]]
+        match = [a for a in cands
+                 if (ag.get_feats(pos.play_move(ag.from_flat(a, env))).transpose(0, 2, 1).reshape(-1) == f).all()]
+        assert len(match) == 1, "leaf features are not those of any child position with the reference's history"

@@ -1,0 +1,189 @@
+"""BASELINE.json configs[3] and configs[4] at their real network depth and shard shape.
+
+configs[3]: GoEnv(19), tower_height=20, 800 readouts, 2048 games on 8 GPUs  -> 256 games per GPU,
+            batches of up to 2048 leaves, exact-f32 tower (Winograd F(3x3,3x3): a 19x19 board is 7x7
+            tiles over a 21x21 padded board, 40 convolutions deep -- where transform error would
+            accumulate if it did).
+configs[4]: same network on the fp16 MFMA path, 1600 readouts, 4096 games -> 512 games per GPU,
+            batches of up to 4096 leaves.
+
+Three kinds of check (VERDICT r1 "Next round" #1):
+  (i)   forward parity at (N=19, tower=20, B=16) against the float64 oracle: f32 <= 1e-4 with both
+        convolution algorithms; fp16 tower against the oracle's restatement of that arithmetic and
+        against f64, measured error printed, bars stated below;
+  (ii)  size-independent invariants of ~30 steps of the real shard shape (no oracle needed);
+  (iii) the first moves of a whole 19x19 / tower-20 game, engine vs oracle tree, bit for bit
+        (the oracle's network callable is the same HIP forward, see tests/gpu_common.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import alphago_jl_amd as ag
+import orc
+from gpu_common import GpuNetForOracle, copy_weights_from_oracle, pos_soa
+from test_gpu_nn import oracle_forward64
+from test_gpu_tree import compare_trees
+from test_hostsim_go import random_positions
+from test_oracle_nn import randomize_bn
+
+pytestmark = pytest.mark.gpu
+L = orc.lib()
+N19, T20 = 19, 20
+TOL = 1e-4                    # north_star: policy/value tensors within 1e-4 fp32
+TOLMIX = 1e-2                 # fp16 tower vs the exact f64 network (test_gpu_nn16.py); measured 8.2e-3 here
+
+
+def _deep_net(seed):
+    rng = np.random.RandomState(seed)
+    onet = L.or_net_new(N19, T20)
+    L.or_net_init_synthetic(onet, 3)
+    randomize_bn(onet, list(range(0, 1 + 2 * T20)) + [orc.L_VALUE_CONV, orc.L_POLICY_CONV], rng)
+    return onet, rng
+
+
+def _positions(rng, B):
+    positions = random_positions(N19, 3, 150, seed=5)
+    return [positions[i] for i in rng.choice(len(positions), B, replace=False)]
+
+
+@pytest.mark.parametrize("winograd", [1, 0])
+def test_c4_forward_f32_tower20_19x19(winograd):
+    B, A = 16, N19 * N19 + 1
+    onet, rng = _deep_net(41)
+    eng = ag.Engine(board_size=N19, games=1, tower_height=T20, num_readouts=8, max_nodes_per_game=16)
+    eng.set_winograd(winograd)
+    copy_weights_from_oracle(eng, onet, T20)
+    positions = _positions(rng, B)
+    feats = np.stack([orc.feats(p).reshape(-1) for p in positions])
+    pi64, v64 = oracle_forward64(onet, feats, A)
+    gpi, gv = eng.forward(*pos_soa(positions))
+    dpi, dv = np.abs(gpi - pi64).max(), np.abs(gv - v64).max()
+    print(f"19x19 tower 20 f32 winograd={winograd}: max|dpi|={dpi:.2e} max|dv|={dv:.2e} "
+          f"(pi max {pi64.max():.3f}, |v| max {np.abs(v64).max():.3f})")
+    assert dpi <= TOL and dv <= TOL, (dpi, dv)
+    assert np.allclose(gpi.sum(1), 1, atol=1e-5)
+    # the answer for a position does not depend on its batch row, also at this size
+    perm = rng.permutation(B)
+    ppi, pv = eng.forward(*pos_soa([positions[i] for i in perm]))
+    assert (ppi == gpi[perm]).all() and (pv == gv[perm]).all()
+    L.or_net_free(onet)
+    eng.close()
+
+
+def test_c5_forward_f16_tower20_19x19():
+    B, A = 16, N19 * N19 + 1
+    onet, rng = _deep_net(42)
+    eng = ag.Engine(board_size=N19, games=1, tower_height=T20, num_readouts=8, max_nodes_per_game=16)
+    copy_weights_from_oracle(eng, onet, T20)
+    eng.set_precision("f16")
+    positions = _positions(rng, B)
+    feats = np.stack([orc.feats(p).reshape(-1) for p in positions]).astype(np.float32)
+    gpi, gv = eng.forward(*pos_soa(positions))
+    pi16, v16 = np.zeros((B, A), np.float32), np.zeros(B, np.float32)
+    L.or_net_forward_feats(onet, orc.fptr(feats), B, orc.fptr(pi16), orc.fptr(v16), 16)
+    pi64, v64 = oracle_forward64(onet, feats, A)
+    # 40 convolutions deep the 5e-4 bar "GPU vs the oracle's restatement of the fp16 arithmetic" of the shallow
+    # tests does not exist any more: f32-vs-f64 accumulation moves an activation across a half rounding boundary
+    # now and then (one half ulp), and those flips propagate through the remaining layers exactly like the fp16
+    # storage error itself does (measured: GPU vs restatement 1.1e-2, each of them vs f64 8e-3).  What can be
+    # held is (a) the stated bar against the exact network and (b) that the GPU's fp16 arithmetic is no further
+    # from the exact network than the oracle's restatement of it is.
+    d16 = max(np.abs(gpi - pi16).max(), np.abs(gv - v16).max())
+    dmix = max(np.abs(gpi - pi64).max(), np.abs(gv - v64).max())
+    dref = max(np.abs(pi16 - pi64).max(), np.abs(v16 - v64).max())
+    print(f"19x19 tower 20 fp16 tower: GPU vs f64 {dmix:.2e} (bar {TOLMIX}); oracle fp16 restatement vs f64 {dref:.2e}; "
+          f"GPU vs restatement {d16:.2e}")
+    assert dmix <= TOLMIX, dmix
+    assert dmix <= 2.0 * dref + 1e-3, (dmix, dref)
+    assert d16 <= dmix + dref + 1e-6
+    assert np.allclose(gpi.sum(1), 1, atol=1e-5)
+    L.or_net_free(onet)
+    eng.close()
+
+
+def _invariants(eng, G, R, steps, par=8):
+    st = eng.stats()
+    assert st["pool_exhausted"] == 0 and st["steps"] == steps
+    assert st["evals"] <= steps * par * G and st["evals"] >= 0.9 * (steps - 1) * par * G     # the batch stays full
+    assert st["root_visits"] >= st["evals"] - G
+    assert st["games_started"] >= G
+    rng = np.random.RandomState(0)
+    for g in rng.choice(G, 12, replace=False):
+        g = int(g)
+        root = eng.tree_root(g)
+        info = eng.node_info(g, root)
+        assert eng.pending_vlosses(g) == 0                                           # mcts_play.jl:92
+        cn = eng.node_floats(g, root, 0)
+        assert (cn >= 0).all() and (cn == np.round(cn)).all()
+        if info.is_expanded:
+            assert info.N == 1 + cn.sum() or info.N == cn.sum()
+            legal = eng.go_legal(eng.node_board(g, root)[None], [info.pos.to_play], [info.pos.ko])[0]
+            assert not (cn[legal == 0] > 0).any()                                    # test_mcts.jl:146-167 at scale
+            prior = eng.node_floats(g, root, 2)
+            assert np.isfinite(prior).all() and abs(prior.sum() - 1.0) < 1e-3
+    return st
+
+
+@pytest.mark.parametrize("precision,R,G", [("f32", 800, 256), ("f16", 1600, 512)])
+def test_c4_c5_full_size_shard_invariants(precision, R, G):
+    """one GPU's shard of configs[3] (f32, 800 readouts, 256 games) / configs[4] (fp16 tower, 1600
+    readouts, 512 games) for 30 steps"""
+    steps = 30
+    eng = ag.Engine(board_size=N19, tower_height=T20, games=G, num_readouts=R, seed=13, stagger_moves=120)
+    eng.init_synthetic(0)
+    eng.set_precision(precision)
+    eng.start(0)
+    eng.step(steps)
+    st = _invariants(eng, G, R, steps)
+    print(f"configs shard {precision}: {st['evals']} evals in {steps} steps, {st['positions']} positions")
+    eng.close()
+
+
+def test_c4_opening_of_a_whole_game_matches_oracle_tree():
+    """19x19 / tower 20: the first 3 moves of a self-play game (48 readouts each, 8 leaves per
+    tree_search!) on the engine's tree and on the oracle's tree, both fed by the HIP network:
+    the complete trees are compared bit for bit after every search and every move."""
+    R, seed, game = 48, 5, 3
+    eng = ag.Engine(board_size=N19, games=1, tower_height=T20, num_readouts=R, seed=seed, max_nodes_per_game=4096)
+    eng.init_synthetic(0)
+    fwd = ag.Engine(board_size=N19, tower_height=T20, games=1, num_readouts=8, max_nodes_per_game=16)
+    fwd.init_synthetic(0)
+    net = GpuNetForOracle(fwd)
+    pos = orc.make_pos(N19)
+    op = L.or_player_new(N19, net.cb, None, R, 0, -0.9, seed, game)
+    L.or_player_initialize_game(op, C.byref(pos))
+    eng.tree_init(0, pos.board_np(), n=0, to_play=1, komi=pos.komi)
+    eng.set_draw(0, game, 0)
+    env = orc.env(N19)
+    A = N19 * N19 + 1
+    for move in range(3):
+        for _ in range(R // 8):
+            no = L.or_player_tree_search(op, 8)
+            ns = eng.tree_search(0, 8)
+            assert ns == no
+        oroot = L.or_player_root(op)
+        d = orc.ODraw(seed, game, L.or_node_pos(oroot).contents.n, 0)
+        L.or_inject_noise(C.byref(env), oroot, C.byref(d))
+        eng.inject_noise(0, eng.tree_root(0))
+        nodes = compare_trees_19(eng, oroot, A)
+        assert nodes > R // 2
+        a = C.c_int()
+        so = L.or_player_pick_move(op, C.byref(a))
+        st, rs = eng.pick_move(0)
+        assert st == so == 0 and rs == a.value
+        assert eng.play_move(0, rs) == L.or_player_play_move(op, rs) == 1
+    L.or_player_free(op)
+    fwd.close()
+    eng.close()
+
+
+def compare_trees_19(eng, oroot, A):
+    """test_gpu_tree.compare_trees is written for the module-level 9x9 action count; same walk here"""
+    import test_gpu_tree as tt
+    old = tt.A
+    tt.A = A
+    try:
+        return compare_trees(eng, 0, eng.tree_root(0), oroot)
+    finally:
+        tt.A = old

@@ -89,3 +89,21 @@ def test_arena_needs_even_slots_on_the_device_path():
             break
     assert sim.counters()["finished"] == 1
     sim.close()
+
+
+def test_arena_pool_exhaustion_is_visible_and_files_every_game_once():
+    """node-pool exhaustion in the arena.  (a) A pool that runs out now and then: every game is
+    still filed exactly once (a side that cannot follow its partner's move raises the pair's abort word and
+    the side that moved files the game as void instead of waiting for ever).  (b) A pool too small to search
+    at all cannot make progress -- that must show in `pool_exhausted` from the first steps on, which is what
+    the selfplay()/evaluate() wrappers poll inside their stepping loops to raise instead of hanging."""
+    N, games = 5, 6
+    black, white = OracleNet(N, 1, seed=0), OracleNet(N, 1, seed=5)
+    recs, ct, steps = run_arena(N, black, white, 24, 4, games, 4, max_steps=20000, max_nodes_per_game=30)
+    assert ct["pool_exhausted"] > 0
+    assert steps < 20000 and len(recs) == games
+    assert sorted(int(r["game_id"]) // 2 for r in recs) == list(range(games))
+    recs, ct, steps = run_arena(N, black, white, 24, 4, games, 4, max_steps=40, max_nodes_per_game=6)
+    assert ct["pool_exhausted"] > 0 and len(recs) == 0
+    black.close()
+    white.close()
