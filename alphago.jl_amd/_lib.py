@@ -143,6 +143,20 @@ def load():
         "agz_net_select": (i32, [E, i32]),
         "agz_records_features": (i32, [E, i64, f32p]),
         "agz_replay_features": (i32, [E, i16p, i64, i32p, i32p, i32, C.c_void_p, i32]),
+        "agz_replay_ingest_packed": (i32, [E, C.c_void_p, i64, i32, P(i64)]),
+        "agz_replay_count": (i64, [E]),
+        "agz_replay_positions": (i64, [E]),
+        "agz_replay_header": (i32, [E, i64, P(GameHeader)]),
+        "agz_replay_game": (i32, [E, i64, i16p, f32p, f32p]),
+        "agz_replay_trim": (i32, [E, i64]),
+        "agz_replay_clear": (i32, [E]),
+        "agz_replay_batch": (i32, [E, P(i64), i32p, i32, C.c_void_p, C.c_void_p, C.c_void_p, i32]),
+        "agz_comm_unique_id": (i32, [P(C.c_uint8)]),
+        "agz_comm_create": (i32, [E, i32, i32, P(C.c_uint8), P(E)]),
+        "agz_comm_destroy": (None, [E]),
+        "agz_allgather_records": (i32, [E, E, P(i64)]),
+        "agz_broadcast_weights": (i32, [E, E, i32, P(i64)]),
+        "agz_abi_layout": (i32, [C.c_char_p, i32p, i32]),
         "agz_tree_init": (i32, [E, i32, i8p, P(PositionInfo), i8p]),
         "agz_tree_root": (i32, [E, i32, i32p]),
         "agz_tree_select_leaf": (i32, [E, i32, i32, i32p]),

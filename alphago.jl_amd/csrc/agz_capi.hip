@@ -1,7 +1,9 @@
 // agz_capi.hip -- the extern "C" surface of libagz.so (include/agz.h): argument checks,
 // exception -> status translation, nothing else.
+#include <cstddef>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "agz_engine.h"
 #include "agz_search.h"
@@ -218,6 +220,116 @@ agz_status agz_records_clear(agz_engine* e) { return guard(e, [&](agz::Engine& E
 agz_status agz_records_features(agz_engine* e, int64_t k, float* out) {
   return guard(e, [&](agz::Engine& E) { E.record_features(k, out); });
 }
+agz_status agz_replay_ingest_packed(agz_engine* e, const void* packed, int64_t nbytes, int32_t is_device,
+                                    int64_t* added_out) {
+  return guard(e, [&](agz::Engine& E) {
+    const int64_t n = E.replay_ingest(packed, nbytes, is_device != 0);
+    if (added_out) *added_out = n;
+  });
+}
+int64_t agz_replay_count(agz_engine* e) { return (e && e->impl) ? e->impl->replay_count() : -1; }
+int64_t agz_replay_positions(agz_engine* e) { return (e && e->impl) ? e->impl->replay_positions() : -1; }
+agz_status agz_replay_header(agz_engine* e, int64_t k, agz_game_header* out) {
+  return guard(e, [&](agz::Engine& E) {
+    AGZ_REQUIRE(out != nullptr, AGZ_BAD_ARGUMENT, "null pointer");
+    E.replay_header(k, out);
+  });
+}
+agz_status agz_replay_game(agz_engine* e, int64_t k, int16_t* moves, float* pis, float* qs) {
+  return guard(e, [&](agz::Engine& E) { E.replay_game(k, moves, pis, qs); });
+}
+agz_status agz_replay_trim(agz_engine* e, int64_t max_positions) {
+  return guard(e, [&](agz::Engine& E) { E.replay_trim(max_positions); });
+}
+agz_status agz_replay_clear(agz_engine* e) { return guard(e, [&](agz::Engine& E) { E.replay_clear(); }); }
+agz_status agz_replay_batch(agz_engine* e, const int64_t* game, const int32_t* ply, int32_t B, float* feats,
+                            float* pi, float* z, int32_t out_is_device) {
+  return guard(e, [&](agz::Engine& E) { E.replay_batch(game, ply, B, feats, pi, z, out_is_device != 0); });
+}
+
+// ---- RCCL exchange (agz_comm.hip)
+agz_status agz_comm_unique_id(uint8_t* id_out) {
+  if (!id_out) return AGZ_BAD_ARGUMENT;
+  try {
+    agz::comm_unique_id(id_out);
+    return AGZ_OK;
+  } catch (const agz::Error& x) {
+    g_create_error = x.what();
+    return x.status;
+  } catch (const std::exception& x) {
+    g_create_error = x.what();
+    return AGZ_RCCL_ERROR;
+  }
+}
+agz_status agz_comm_create(agz_engine* e, int32_t rank, int32_t world, const uint8_t* id, agz_comm** out) {
+  if (!out) return AGZ_BAD_ARGUMENT;
+  *out = nullptr;
+  return guard(e, [&](agz::Engine& E) { *out = reinterpret_cast<agz_comm*>(agz::comm_create(E, rank, world, id)); });
+}
+void agz_comm_destroy(agz_comm* c) { agz::comm_destroy(reinterpret_cast<agz::Comm*>(c)); }
+agz_status agz_allgather_records(agz_engine* e, agz_comm* comm, int64_t* added_out) {
+  return guard(e, [&](agz::Engine& E) {
+    const int64_t n = agz::comm_allgather_records(E, reinterpret_cast<agz::Comm*>(comm));
+    if (added_out) *added_out = n;
+  });
+}
+agz_status agz_broadcast_weights(agz_engine* e, agz_comm* comm, int32_t root, int64_t* nfloats_out) {
+  return guard(e, [&](agz::Engine& E) {
+    const int64_t n = agz::comm_broadcast_weights(E, reinterpret_cast<agz::Comm*>(comm), root);
+    if (nfloats_out) *nfloats_out = n;
+  });
+}
+
+// ---- ABI self-description
+int32_t agz_abi_layout(const char* name, int32_t* out, int32_t cap) {
+  if (!name || !out) return -1;
+  std::vector<int32_t> v;
+#define AGZ_SZ(T) v.push_back((int32_t)sizeof(T))
+#define AGZ_OFF(T, f) v.push_back((int32_t)offsetof(T, f))
+  const std::string n(name);
+  if (n == "agz_config") {
+    AGZ_SZ(agz_config);
+    AGZ_OFF(agz_config, board_size); AGZ_OFF(agz_config, tower_height); AGZ_OFF(agz_config, games);
+    AGZ_OFF(agz_config, num_readouts); AGZ_OFF(agz_config, parallel_readouts); AGZ_OFF(agz_config, two_player_mode);
+    AGZ_OFF(agz_config, komi); AGZ_OFF(agz_config, reserved0); AGZ_OFF(agz_config, c_puct);
+    AGZ_OFF(agz_config, dirichlet_noise_weight); AGZ_OFF(agz_config, resign_threshold);
+    AGZ_OFF(agz_config, resign_disable_fraction); AGZ_OFF(agz_config, seed); AGZ_OFF(agz_config, game_id_base);
+    AGZ_OFF(agz_config, game_id_stride); AGZ_OFF(agz_config, max_nodes_per_game); AGZ_OFF(agz_config, device);
+    AGZ_OFF(agz_config, external_network); AGZ_OFF(agz_config, stagger_moves);
+    AGZ_OFF(agz_config, record_capacity_games); AGZ_OFF(agz_config, arena_mode);
+  } else if (n == "agz_stats") {
+    AGZ_SZ(agz_stats);
+    AGZ_OFF(agz_stats, steps); AGZ_OFF(agz_stats, positions); AGZ_OFF(agz_stats, games_started);
+    AGZ_OFF(agz_stats, games_finished); AGZ_OFF(agz_stats, evals); AGZ_OFF(agz_stats, duplicate_evals);
+    AGZ_OFF(agz_stats, terminal_visits); AGZ_OFF(agz_stats, root_visits); AGZ_OFF(agz_stats, nodes_in_use);
+    AGZ_OFF(agz_stats, pool_exhausted); AGZ_OFF(agz_stats, resigned_games); AGZ_OFF(agz_stats, live_games);
+    AGZ_OFF(agz_stats, records_dropped);
+  } else if (n == "agz_game_header") {
+    AGZ_SZ(agz_game_header);
+    AGZ_OFF(agz_game_header, game_id); AGZ_OFF(agz_game_header, num_moves); AGZ_OFF(agz_game_header, result);
+    AGZ_OFF(agz_game_header, was_resign); AGZ_OFF(agz_game_header, resign_disabled);
+    AGZ_OFF(agz_game_header, final_score); AGZ_OFF(agz_game_header, reserved);
+  } else if (n == "agz_position_info") {
+    AGZ_SZ(agz_position_info);
+    AGZ_OFF(agz_position_info, n); AGZ_OFF(agz_position_info, to_play); AGZ_OFF(agz_position_info, ko);
+    AGZ_OFF(agz_position_info, caps_black); AGZ_OFF(agz_position_info, caps_white);
+    AGZ_OFF(agz_position_info, last_move); AGZ_OFF(agz_position_info, prev_move);
+    AGZ_OFF(agz_position_info, history_len); AGZ_OFF(agz_position_info, komi);
+  } else if (n == "agz_node_info") {
+    AGZ_SZ(agz_node_info);
+    AGZ_OFF(agz_node_info, N); AGZ_OFF(agz_node_info, W); AGZ_OFF(agz_node_info, Q); AGZ_OFF(agz_node_info, parent);
+    AGZ_OFF(agz_node_info, fmove); AGZ_OFF(agz_node_info, is_expanded); AGZ_OFF(agz_node_info, losses_applied);
+    AGZ_OFF(agz_node_info, done); AGZ_OFF(agz_node_info, pos);
+  } else {
+    return -1;
+  }
+#undef AGZ_SZ
+#undef AGZ_OFF
+  if ((int32_t)v.size() > cap) return -1;
+  for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+  return (int32_t)v.size() - 1;
+}
+
 agz_status agz_replay_features(agz_engine* e, const int16_t* moves, int64_t nmoves, const int32_t* game_offset,
                                const int32_t* ply, int32_t B, float* out, int32_t out_is_device) {
   return guard(e, [&](agz::Engine& E) {

@@ -1,0 +1,184 @@
+// agz_comm.hip -- the ONE exchange step of the path, behind the C ABI: an RCCL all-gather over
+// xGMI of the finished (moves, pi, q, z) records of every rank into every rank's device replay arena, plus the
+// optional weight broadcast from the training rank.  Self-play itself has no collective (games are independent,
+// /root/reference/src/train.jl:56-57); the caller this serves is the replay-buffer fill of train.jl:56-66.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1, no link-time dependency): libagz.so must load and export
+// its symbols on a host without RCCL/GPUs, and a process that already carries a copy of RCCL (a PyTorch wheel
+// bundles its own) must end up with ONE instance -- dlopen by soname returns that one.
+//
+// Shape of the exchange (records are variable-length, ranks finish different numbers of games):
+//   1. every rank packs its finished records into one device buffer            (k_pack_records)
+//   2. ncclAllGather of {records, bytes} per rank                               (16 B per rank)
+//   3. ncclAllGather of the payload padded to the largest rank                  (device -> device)
+//   4. one wave per rank walks that rank's chunk to index the records           (k_index_records)
+//   5. the chunks are compacted into the arena; only the index (40 B per game) visits the host.
+// With 7 x 153 GB/s xGMI links per GPU a BASELINE configs[2] generation (8192 games, ~0.25 GB) is a
+// sub-millisecond transfer: one large collective, not one per game.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "agz_engine.h"
+
+namespace agz {
+
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+static Rccl& rccl() {
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (R.lib) break;
+    }
+    if (!R.lib) {
+      R.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "?");
+      return;
+    }
+    auto sym = [&](const char* s) {
+      void* p = dlsym(R.lib, s);
+      if (!p && R.error.empty()) R.error = std::string("RCCL symbol missing: ") + s;
+      return p;
+    };
+    R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+    R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+    R.AllGather = (decltype(R.AllGather))sym("ncclAllGather");
+    R.Broadcast = (decltype(R.Broadcast))sym("ncclBroadcast");
+    R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+  });
+  AGZ_REQUIRE(R.error.empty(), AGZ_RCCL_ERROR, "%s", R.error.c_str());
+  return R;
+}
+
+#define AGZ_RCCL(expr)                                                                                    \
+  do {                                                                                                    \
+    ncclResult_t _r = (expr);                                                                             \
+    if (_r != ncclSuccess)                                                                                \
+      throw ::agz::Error(AGZ_RCCL_ERROR, ::agz::fmt("%s failed: %s (%s:%d)", #expr,                       \
+                                                    rccl().GetErrorString ? rccl().GetErrorString(_r) : "?", \
+                                                    __FILE__, __LINE__));                                 \
+  } while (0)
+
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  Engine* engine = nullptr;
+  DevBuf<int64_t> d_counts;     // [1 + world][2]: mine, then everybody's {records, bytes}
+  DevBuf<uint8_t> d_recv;
+};
+
+void comm_unique_id(uint8_t* out) {
+  static_assert(AGZ_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "agz.h and rccl.h disagree on the id size");
+  ncclUniqueId id;
+  AGZ_RCCL(rccl().GetUniqueId(&id));
+  std::memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
+}
+
+Comm* comm_create(Engine& E, int rank, int world, const uint8_t* idbytes) {
+  AGZ_REQUIRE(world >= 1 && rank >= 0 && rank < world, AGZ_BAD_ARGUMENT, "rank %d of %d", rank, world);
+  AGZ_REQUIRE(idbytes != nullptr, AGZ_BAD_ARGUMENT, "null unique id");
+  AGZ_HIP(hipSetDevice(E.config().device));
+  ncclUniqueId id;
+  std::memcpy(id.internal, idbytes, NCCL_UNIQUE_ID_BYTES);
+  std::unique_ptr<Comm> c(new Comm);
+  c->rank = rank;
+  c->world = world;
+  c->engine = &E;
+  AGZ_RCCL(rccl().CommInitRank(&c->comm, world, id, rank));
+  c->d_counts.alloc((size_t)2 * (1 + world));
+  return c.release();
+}
+
+void comm_destroy(Comm* c) {
+  if (!c) return;
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  delete c;
+}
+
+// records of every rank -> this rank's replay arena, rank order; returns the number of games added
+int64_t comm_allgather_records(Engine& E, Comm* c) {
+  if (!c) return E.replay_ingest_local();     // no communicator: a single-GPU run files its own records
+  AGZ_REQUIRE(c->engine == &E, AGZ_BAD_ARGUMENT, "communicator belongs to another engine");
+  hipStream_t s = E.stream();
+  const int W = c->world;
+  // 1. pack
+  const int64_t need = E.records_packed_size();
+  DevBuf<uint8_t>& send = E.pack_scratch();
+  int64_t nb = 0, nrec = 0;
+  if (need) {
+    send.ensure((size_t)need);
+    nrec = E.pack_records_device(send.p, need, &nb);
+  }
+  // 2. counts
+  const int64_t mine[2] = {nrec, nb};
+  AGZ_HIP(hipMemcpyAsync(c->d_counts.p, mine, sizeof(mine), hipMemcpyHostToDevice, s));
+  AGZ_RCCL(rccl().AllGather(c->d_counts.p, c->d_counts.p + 2, 2, ncclInt64, c->comm, s));
+  std::vector<int64_t> counts((size_t)2 * W);
+  AGZ_HIP(hipMemcpyAsync(counts.data(), c->d_counts.p + 2, sizeof(int64_t) * counts.size(), hipMemcpyDeviceToHost, s));
+  AGZ_HIP(hipStreamSynchronize(s));
+  int64_t mx = 0, total = 0;
+  for (int r = 0; r < W; ++r) {
+    AGZ_REQUIRE(counts[2 * r] >= 0 && counts[2 * r + 1] >= 0 && counts[2 * r + 1] % 8 == 0, AGZ_RCCL_ERROR,
+                "rank %d announced %lld records in %lld bytes", r, (long long)counts[2 * r], (long long)counts[2 * r + 1]);
+    mx = std::max(mx, counts[2 * r + 1]);
+    total += counts[2 * r];
+  }
+  if (total == 0) return 0;
+  mx = (mx + 255) & ~(int64_t)255;
+  // 3. payload, padded to the largest rank (the pad bytes are never read: step 4 stops at each rank's count)
+  if ((int64_t)send.n < mx) {
+    DevBuf<uint8_t> bigger;
+    bigger.alloc((size_t)mx);
+    if (nb) AGZ_HIP(hipMemcpyAsync(bigger.p, send.p, (size_t)nb, hipMemcpyDeviceToDevice, s));
+    AGZ_HIP(hipStreamSynchronize(s));
+    std::swap(bigger.p, send.p);
+    std::swap(bigger.n, send.n);
+  }
+  c->d_recv.ensure((size_t)mx * W);
+  AGZ_RCCL(rccl().AllGather(send.p, c->d_recv.p, (size_t)mx, ncclUint8, c->comm, s));
+  // 4 + 5. index on the device, compact into the arena
+  std::vector<int64_t> coff((size_t)W), cbytes((size_t)W), cnrec((size_t)W);
+  for (int r = 0; r < W; ++r) {
+    coff[r] = (int64_t)r * mx;
+    cnrec[r] = counts[2 * r];
+    cbytes[r] = counts[2 * r + 1];
+  }
+  return E.replay_ingest_chunks(c->d_recv.p, coff, cbytes, cnrec);
+}
+
+// rank `root`'s parameters overwrite every other rank's replica (one flat f32 broadcast, 12-24 M parameters)
+int64_t comm_broadcast_weights(Engine& E, Comm* c, int root) {
+  AGZ_REQUIRE(c != nullptr, AGZ_BAD_ARGUMENT, "null communicator");
+  AGZ_REQUIRE(c->engine == &E, AGZ_BAD_ARGUMENT, "communicator belongs to another engine");
+  AGZ_REQUIRE(root >= 0 && root < c->world, AGZ_BAD_ARGUMENT, "root %d of %d", root, c->world);
+  hipStream_t s = E.stream();
+  std::vector<float> w = E.weights_flat();
+  DevBuf<float> d;
+  d.alloc(w.size());
+  if (c->rank == root) AGZ_HIP(hipMemcpyAsync(d.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice, s));
+  AGZ_RCCL(rccl().Broadcast(d.p, d.p, w.size(), ncclFloat32, root, c->comm, s));
+  if (c->rank != root) {
+    AGZ_HIP(hipMemcpyAsync(w.data(), d.p, sizeof(float) * w.size(), hipMemcpyDeviceToHost, s));
+    AGZ_HIP(hipStreamSynchronize(s));
+    E.weights_set_flat(w);
+  }
+  AGZ_HIP(hipStreamSynchronize(s));
+  return (int64_t)w.size();
+}
+
+}  // namespace agz

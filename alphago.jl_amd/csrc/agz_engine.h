@@ -41,7 +41,27 @@ class Engine {
   int64_t records_packed_size();
   void records_export_packed(void* dst, int64_t capacity, bool is_device);
   void records_clear();
+  int64_t pack_records_device(uint8_t* dst, int64_t capacity, int64_t* nbytes);
   void record_features(int64_t k, float* out);
+
+  // device replay arena: finished games of every rank, packed, resident in HBM
+  int64_t replay_ingest(const void* packed, int64_t nbytes, bool is_device);
+  int64_t replay_ingest_local();
+  int64_t replay_ingest_chunks(const uint8_t* dbuf, const std::vector<int64_t>& coff,
+                               const std::vector<int64_t>& cbytes, const std::vector<int64_t>& cnrec);
+  int64_t replay_count() const { return (int64_t)rp_hdr_.size(); }
+  int64_t replay_positions() const { return rp_positions_; }
+  int64_t replay_bytes() const { return (int64_t)rp_used_; }
+  void replay_header(int64_t k, agz_game_header* out) const;
+  void replay_game(int64_t k, int16_t* moves, float* pis, float* qs);
+  void replay_trim(int64_t max_positions);
+  void replay_clear();
+  void replay_batch(const int64_t* game, const int32_t* ply, int B, float* feats, float* pi, float* z,
+                    bool out_is_device);
+  DevBuf<uint8_t>& pack_scratch() { return s_pack_; }
+  // flat parameter vector of the selected network in layers() order (broadcast_weights)
+  std::vector<float> weights_flat();
+  void weights_set_flat(const std::vector<float>& w);
   void replay_batch_features(const int16_t* moves, int64_t nmoves, const int32_t* off, const int32_t* ply, int B,
                              float* out, bool out_is_device);
 
@@ -82,6 +102,7 @@ class Engine {
   std::string last_error;
 
  private:
+  void replay_reserve(size_t bytes);
   void upload_view_outputs();
   void fill_synthetic_inputs(int B);
   void check_game(int g) const;
@@ -108,6 +129,20 @@ class Engine {
   DevBuf<int32_t> s_iout_;
   int external_batch_ = 0;
   int tree_batch_ = 0;
+  // replay arena
+  DevBuf<uint8_t> rp_buf_, s_pack_;
+  size_t rp_used_ = 0;
+  int64_t rp_positions_ = 0;
+  std::vector<int64_t> rp_off_;
+  std::vector<agz_game_header> rp_hdr_;
 };
+
+// RCCL exchange (agz_comm.hip)
+struct Comm;
+void comm_unique_id(uint8_t* out);
+Comm* comm_create(Engine& E, int rank, int world, const uint8_t* id);
+void comm_destroy(Comm* c);
+int64_t comm_allgather_records(Engine& E, Comm* c);
+int64_t comm_broadcast_weights(Engine& E, Comm* c, int root);
 
 }  // namespace agz

@@ -215,19 +215,10 @@ __global__ __launch_bounds__(kWave) void k_go_score(View V, const int8_t* boards
 // the empty board and writes the features of the position BEFORE move k for every k >= emit_from[b]
 // to out + out_off[b] + (k - emit_from[b]) * 17*P.  (record_features: one block, emit_from 0;
 // get_replay_batch, train.jl:4-12: one block per sampled (game, ply), nm = ply+1, emit_from = ply.)
-__global__ __launch_bounds__(kWave) void k_replay_features(View V, const int16_t* moves, const int32_t* off,
-                                                            const int32_t* nms, const int32_t* emit_from,
-                                                            const int64_t* out_off,
-                                                            int8_t* hist_all /*[blocks][8][PP] scratch in HBM*/,
-                                                            float* out_all) {
-  AGZ_SCRATCH(S)
-  HipWave w;
+template <class W>
+__device__ __forceinline__ void replay_emit(W& w, const View& V, Scratch& S, const int16_t* moves, int nm, int from,
+                                            int8_t* hist, float* out) {
   const int P = V.P;
-  const int b = blockIdx.x;
-  moves += off[b];
-  const int nm = nms[b], from = emit_from[b];
-  int8_t* hist = hist_all + (long)b * 8 * V.PP;
-  float* out = out_all + out_off[b];
   // hist[0] = current board, hist[k] = k moves ago; avail = number of real older boards
   w.for_each(8 * V.PP, [&](int i) { hist[i] = 0; });
   w.sync();
@@ -266,6 +257,93 @@ __global__ __launch_bounds__(kWave) void k_replay_features(View V, const int16_t
     tp = -tp;
     if (avail < 7) avail++;
   }
+}
+
+__global__ __launch_bounds__(kWave) void k_replay_features(View V, const int16_t* moves, const int32_t* off,
+                                                            const int32_t* nms, const int32_t* emit_from,
+                                                            const int64_t* out_off,
+                                                            int8_t* hist_all /*[blocks][8][PP] scratch in HBM*/,
+                                                            float* out_all) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  const int b = blockIdx.x;
+  replay_emit(w, V, S, moves + off[b], nms[b], emit_from[b], hist_all + (long)b * 8 * V.PP, out_all + out_off[b]);
+}
+
+// ---- the device replay arena (agz_replay_*): packed records
+//      [agz_game_header 32 B | moves i16[n] | pad 4 | pis f32[n][A] | qs f32[n] | pad 8] back to back in HBM.
+
+__host__ __device__ inline size_t packed_bytes(int A, int nm) {
+  size_t b = sizeof(agz_game_header) + sizeof(int16_t) * (size_t)nm;
+  b = (b + 3) & ~(size_t)3;
+  b += sizeof(float) * (size_t)nm * A + sizeof(float) * (size_t)nm;
+  return (b + 7) & ~(size_t)7;
+}
+
+// one workgroup per finished record k: copy it from the engine's record ring into dst + off[k]
+__global__ __launch_bounds__(256) void k_pack_records(View V, const int64_t* off, uint8_t* dst) {
+  const long k = blockIdx.x;
+  const agz_game_header h = V.fin_hdr[k];
+  const int nm = h.num_moves, mgl = V.max_game_length, A = V.A;
+  uint8_t* r = dst + off[k];
+  if (threadIdx.x == 0) *reinterpret_cast<agz_game_header*>(r) = h;
+  int16_t* mv = reinterpret_cast<int16_t*>(r + sizeof(agz_game_header));
+  const size_t o_pi = (sizeof(agz_game_header) + sizeof(int16_t) * (size_t)nm + 3) & ~(size_t)3;
+  float* pi = reinterpret_cast<float*>(r + o_pi);
+  float* q = pi + (size_t)nm * A;
+  for (int i = threadIdx.x; i < nm; i += 256) {
+    mv[i] = V.fin_moves[k * mgl + i];
+    q[i] = V.fin_q[k * mgl + i];
+  }
+  if ((nm & 1) && threadIdx.x == 0) mv[nm] = 0;                       // the 2 pad bytes in front of pis
+  for (long i = threadIdx.x; i < (long)nm * A; i += 256) pi[i] = V.fin_pi[k * (long)mgl * A + i];
+  const size_t end = o_pi + sizeof(float) * (size_t)nm * (A + 1);
+  if ((end & 7) && threadIdx.x == 0) *reinterpret_cast<uint32_t*>(r + end) = 0u;   // pad to 8
+}
+
+// one wave per source chunk (= one rank's part of the padded all-gather): walk its records and write where
+// each one starts: out_off[first[c] + i] = byte offset of record i of chunk c inside `buf`.  nrec[c] >= 0 is
+// the record count the sender announced (checked); nrec[c] = -(cap + 1) means "unknown, at most cap".
+__global__ __launch_bounds__(kWave) void k_index_records(const uint8_t* buf, const int64_t* chunk_off,
+                                                          const int64_t* chunk_bytes, const int64_t* nrec,
+                                                          const int64_t* first, int A, int mgl, int64_t* out_off,
+                                                          agz_game_header* out_hdr, int64_t* found, int32_t* bad) {
+  if (threadIdx.x != 0) return;
+  const int c = blockIdx.x;
+  int64_t o = chunk_off[c];
+  const int64_t end = o + chunk_bytes[c];
+  const int64_t want = nrec[c], cap = want < 0 ? -(want + 1) : want;
+  int64_t i = 0;
+  bool ok = true;
+  while (o < end) {
+    if (i >= cap || o + (int64_t)sizeof(agz_game_header) > end) { ok = false; break; }
+    const agz_game_header h = *reinterpret_cast<const agz_game_header*>(buf + o);
+    if (h.num_moves < 0 || h.num_moves > mgl || o + (int64_t)packed_bytes(A, h.num_moves) > end) { ok = false; break; }
+    out_off[first[c] + i] = o;
+    out_hdr[first[c] + i] = h;
+    o += (int64_t)packed_bytes(A, h.num_moves);
+    ++i;
+  }
+  if (!ok || o != end || (want >= 0 && i != want)) atomicAdd(bad, 1);
+  found[c] = i;
+}
+
+// get_replay_batch (train.jl:4-12) straight from the arena: sample b = (record at rec_off[b], ply[b]):
+// features of the position before move ply (replay_position, board.jl:557-578), pi of that move, z = result
+__global__ __launch_bounds__(kWave) void k_replay_arena_batch(View V, const uint8_t* arena, const int64_t* rec_off,
+                                                               const int32_t* ply, int8_t* hist_all, float* feats,
+                                                               float* pi_out, float* z_out) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  const int b = blockIdx.x, A = V.A;
+  const uint8_t* r = arena + rec_off[b];
+  const agz_game_header h = *reinterpret_cast<const agz_game_header*>(r);
+  const int16_t* mv = reinterpret_cast<const int16_t*>(r + sizeof(agz_game_header));
+  const size_t o_pi = (sizeof(agz_game_header) + sizeof(int16_t) * (size_t)h.num_moves + 3) & ~(size_t)3;
+  const float* pi = reinterpret_cast<const float*>(r + o_pi) + (size_t)ply[b] * A;
+  replay_emit(w, V, S, mv, ply[b] + 1, ply[b], hist_all + (long)b * 8 * V.PP, feats + (long)b * 17 * V.P);
+  if (pi_out) w.for_each(A, [&](int i) { pi_out[(long)b * A + i] = pi[i]; });
+  if (z_out && w.leader()) z_out[b] = (float)h.result;
 }
 
 __global__ void k_debug_draws(uint64_t seed, uint64_t game, uint32_t move, int n, double alpha, double* out) {
@@ -493,12 +571,7 @@ void Engine::record_game(int64_t k, int16_t* moves, float* pis, float* qs) {
   AGZ_HIP(hipStreamSynchronize(stream_));
 }
 
-static size_t packed_record_bytes(const View& V, int nm) {
-  size_t b = sizeof(agz_game_header) + sizeof(int16_t) * (size_t)nm;
-  b = (b + 3) & ~(size_t)3;
-  b += sizeof(float) * (size_t)nm * V.A + sizeof(float) * (size_t)nm;
-  return (b + 7) & ~(size_t)7;
-}
+static size_t packed_record_bytes(const View& V, int nm) { return packed_bytes(V.A, nm); }
 
 int64_t Engine::records_packed_size() {
   const int64_t n = records_count();
@@ -509,28 +582,260 @@ int64_t Engine::records_packed_size() {
   return (int64_t)total;
 }
 
-void Engine::records_export_packed(void* dst, int64_t capacity, bool is_device) {
+// pack every finished record into `dst` (device memory, >= records_packed_size() bytes): one D2H of the
+// headers to lay the records out, one kernel to move them.  Returns the record count.
+int64_t Engine::pack_records_device(uint8_t* dst, int64_t capacity, int64_t* nbytes) {
   const int64_t n = records_count();
+  *nbytes = 0;
+  if (n == 0) return 0;
   std::vector<agz_game_header> h((size_t)n);
-  if (n) AGZ_HIP(hipMemcpy(h.data(), V_.fin_hdr, sizeof(agz_game_header) * (size_t)n, hipMemcpyDeviceToHost));
-  const size_t mgl = V_.max_game_length;
-  const hipMemcpyKind kd = is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-  const hipMemcpyKind kh = is_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
-  size_t off = 0;
-  char* out = (char*)dst;
+  AGZ_HIP(hipMemcpyAsync(h.data(), V_.fin_hdr, sizeof(agz_game_header) * (size_t)n, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  std::vector<int64_t> off((size_t)n);
+  size_t total = 0;
   for (int64_t k = 0; k < n; ++k) {
-    const size_t nm = (size_t)h[k].num_moves, need = packed_record_bytes(V_, (int)nm);
-    AGZ_REQUIRE((int64_t)(off + need) <= capacity, AGZ_BAD_ARGUMENT, "export buffer too small");
-    size_t o = off;
-    AGZ_HIP(hipMemcpyAsync(out + o, &h[k], sizeof(agz_game_header), kh, stream_));
-    o += sizeof(agz_game_header);
-    if (nm) AGZ_HIP(hipMemcpyAsync(out + o, V_.fin_moves + k * mgl, sizeof(int16_t) * nm, kd, stream_));
-    o += sizeof(int16_t) * nm;
-    o = (o + 3) & ~(size_t)3;
-    if (nm) AGZ_HIP(hipMemcpyAsync(out + o, V_.fin_pi + k * mgl * V_.A, sizeof(float) * nm * V_.A, kd, stream_));
-    o += sizeof(float) * nm * V_.A;
-    if (nm) AGZ_HIP(hipMemcpyAsync(out + o, V_.fin_q + k * mgl, sizeof(float) * nm, kd, stream_));
-    off += need;
+    off[k] = (int64_t)total;
+    total += packed_record_bytes(V_, h[k].num_moves);
+  }
+  AGZ_REQUIRE((int64_t)total <= capacity, AGZ_BAD_ARGUMENT, "export buffer too small");
+  s_i64a_.ensure((size_t)n);
+  AGZ_HIP(hipMemcpyAsync(s_i64a_.p, off.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)n), dim3(256), 0, stream_, V_, (const int64_t*)s_i64a_.p, dst);
+  AGZ_HIP(hipGetLastError());
+  AGZ_HIP(hipStreamSynchronize(stream_));      // `off` is stack-owned
+  *nbytes = (int64_t)total;
+  return n;
+}
+
+void Engine::records_export_packed(void* dst, int64_t capacity, bool is_device) {
+  int64_t nb = 0;
+  if (is_device) {
+    pack_records_device((uint8_t*)dst, capacity, &nb);
+    return;
+  }
+  const int64_t need = records_packed_size();
+  AGZ_REQUIRE(need <= capacity, AGZ_BAD_ARGUMENT, "export buffer too small");
+  if (need == 0) return;
+  s_pack_.ensure((size_t)need);
+  pack_records_device(s_pack_.p, need, &nb);
+  AGZ_HIP(hipMemcpyAsync(dst, s_pack_.p, (size_t)nb, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- device replay arena
+
+void Engine::replay_reserve(size_t bytes) {
+  if (bytes <= rp_buf_.n) return;
+  size_t cap = std::max<size_t>(bytes, std::max<size_t>(2 * rp_buf_.n, (size_t)1 << 20));
+  DevBuf<uint8_t> nb;
+  nb.alloc(cap);
+  if (rp_used_) AGZ_HIP(hipMemcpyAsync(nb.p, rp_buf_.p, rp_used_, hipMemcpyDeviceToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  std::swap(nb.p, rp_buf_.p);
+  std::swap(nb.n, rp_buf_.n);
+}
+
+// Append packed records lying in device memory as `chunks` (offset, bytes, expected record count or -1) of
+// `dbuf` -- a padded all-gather receive buffer has one chunk per rank.  The variable-length records are
+// indexed ON THE DEVICE (one wave walks one chunk); only the index (8 B + 32 B per game) visits the host.
+int64_t Engine::replay_ingest_chunks(const uint8_t* dbuf, const std::vector<int64_t>& coff,
+                                     const std::vector<int64_t>& cbytes, const std::vector<int64_t>& cnrec) {
+  const int nc = (int)coff.size();
+  int64_t total_rec = 0, total_bytes = 0;
+  std::vector<int64_t> first((size_t)nc), nrec(cnrec);
+  for (int c = 0; c < nc; ++c) {
+    // an unknown count is bounded by the smallest record (a bare header)
+    if (nrec[c] < 0) nrec[c] = -(cbytes[c] / (int64_t)sizeof(agz_game_header)) - 1;
+    first[c] = total_rec;
+    total_rec += nrec[c] < 0 ? -(nrec[c] + 1) : nrec[c];
+    total_bytes += cbytes[c];
+  }
+  if (total_rec == 0 || total_bytes == 0) return 0;
+  // device scratch: [coff | cbytes | nrec | first] int64 x nc, then offsets, found counts, bad flag, headers
+  DevBuf<int64_t> d_meta, d_off;
+  DevBuf<agz_game_header> d_hdr;
+  DevBuf<int32_t> d_flag;
+  d_meta.alloc((size_t)5 * nc);
+  d_off.alloc((size_t)total_rec);
+  d_hdr.alloc((size_t)total_rec);
+  d_flag.alloc(1);
+  std::vector<int64_t> meta;
+  meta.insert(meta.end(), coff.begin(), coff.end());
+  meta.insert(meta.end(), cbytes.begin(), cbytes.end());
+  meta.insert(meta.end(), nrec.begin(), nrec.end());
+  meta.insert(meta.end(), first.begin(), first.end());
+  meta.resize((size_t)5 * nc, 0);
+  AGZ_HIP(hipMemcpyAsync(d_meta.p, meta.data(), sizeof(int64_t) * meta.size(), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemsetAsync(d_flag.p, 0, sizeof(int32_t), stream_));
+  hipLaunchKernelGGL(k_index_records, dim3(nc), dim3(kWave), 0, stream_, dbuf, (const int64_t*)d_meta.p,
+                     (const int64_t*)(d_meta.p + nc), (const int64_t*)(d_meta.p + 2 * nc),
+                     (const int64_t*)(d_meta.p + 3 * nc), V_.A, V_.max_game_length, d_off.p, d_hdr.p, d_meta.p + 4 * nc,
+                     d_flag.p);
+  AGZ_HIP(hipGetLastError());
+  std::vector<int64_t> off((size_t)total_rec), found((size_t)nc);
+  std::vector<agz_game_header> hdr((size_t)total_rec);
+  int32_t bad = 0;
+  AGZ_HIP(hipMemcpyAsync(off.data(), d_off.p, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(hdr.data(), d_hdr.p, sizeof(agz_game_header) * hdr.size(), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(found.data(), d_meta.p + 4 * nc, sizeof(int64_t) * nc, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(&bad, d_flag.p, sizeof(bad), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  AGZ_REQUIRE(bad == 0, AGZ_BAD_ARGUMENT, "packed records are malformed (a record runs past its chunk or a count does not match)");
+  replay_reserve(rp_used_ + (size_t)total_bytes);
+  int64_t added = 0;
+  for (int c = 0; c < nc; ++c) {
+    if (cbytes[c] == 0) continue;
+    AGZ_HIP(hipMemcpyAsync(rp_buf_.p + rp_used_, dbuf + coff[c], (size_t)cbytes[c], hipMemcpyDeviceToDevice, stream_));
+    for (int64_t i = 0; i < found[c]; ++i) {
+      rp_off_.push_back((int64_t)rp_used_ + off[first[c] + i] - coff[c]);
+      rp_hdr_.push_back(hdr[first[c] + i]);
+      rp_positions_ += hdr[first[c] + i].num_moves;
+    }
+    added += found[c];
+    rp_used_ += (size_t)cbytes[c];
+  }
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  return added;
+}
+
+int64_t Engine::replay_ingest(const void* packed, int64_t nbytes, bool is_device) {
+  AGZ_REQUIRE(nbytes >= 0 && (nbytes == 0 || packed), AGZ_BAD_ARGUMENT, "bad packed buffer");
+  AGZ_REQUIRE(nbytes % 8 == 0, AGZ_BAD_ARGUMENT, "packed records are a multiple of 8 bytes");
+  if (nbytes == 0) return 0;
+  const uint8_t* d = (const uint8_t*)packed;
+  if (!is_device) {
+    s_pack_.ensure((size_t)nbytes);
+    AGZ_HIP(hipMemcpyAsync(s_pack_.p, packed, (size_t)nbytes, hipMemcpyHostToDevice, stream_));
+    d = s_pack_.p;
+  }
+  return replay_ingest_chunks(d, {0}, {nbytes}, {-1});
+}
+
+int64_t Engine::replay_ingest_local() {
+  const int64_t need = records_packed_size();
+  if (need == 0) return 0;
+  s_pack_.ensure((size_t)need);
+  int64_t nb = 0;
+  const int64_t n = pack_records_device(s_pack_.p, need, &nb);
+  return replay_ingest_chunks(s_pack_.p, {0}, {nb}, {n});
+}
+
+void Engine::replay_header(int64_t k, agz_game_header* out) const {
+  AGZ_REQUIRE(k >= 0 && k < (int64_t)rp_hdr_.size(), AGZ_BAD_ARGUMENT, "replay game %lld out of range", (long long)k);
+  *out = rp_hdr_[(size_t)k];
+}
+
+void Engine::replay_game(int64_t k, int16_t* moves, float* pis, float* qs) {
+  agz_game_header h;
+  replay_header(k, &h);
+  const size_t nm = (size_t)h.num_moves;
+  if (nm == 0) return;
+  const uint8_t* r = rp_buf_.p + rp_off_[(size_t)k];
+  const size_t o_pi = (sizeof(agz_game_header) + sizeof(int16_t) * nm + 3) & ~(size_t)3;
+  if (moves) AGZ_HIP(hipMemcpyAsync(moves, r + sizeof(agz_game_header), sizeof(int16_t) * nm, hipMemcpyDeviceToHost, stream_));
+  if (pis) AGZ_HIP(hipMemcpyAsync(pis, r + o_pi, sizeof(float) * nm * V_.A, hipMemcpyDeviceToHost, stream_));
+  if (qs) AGZ_HIP(hipMemcpyAsync(qs, r + o_pi + sizeof(float) * nm * V_.A, sizeof(float) * nm, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+// the FIFO window of train() (`shrink`, train.jl:52): forget the oldest games until at most max_positions remain
+void Engine::replay_trim(int64_t max_positions) {
+  AGZ_REQUIRE(max_positions >= 0, AGZ_BAD_ARGUMENT, "negative window");
+  size_t drop = 0;
+  int64_t pos = rp_positions_;
+  while (drop < rp_hdr_.size() && pos > max_positions) pos -= rp_hdr_[drop++].num_moves;
+  if (drop == 0) return;
+  if (drop == rp_hdr_.size()) { replay_clear(); return; }
+  const size_t cut = (size_t)rp_off_[drop], keep = rp_used_ - cut;
+  DevBuf<uint8_t> nb;
+  nb.alloc(std::max(keep, (size_t)1 << 20));
+  AGZ_HIP(hipMemcpyAsync(nb.p, rp_buf_.p + cut, keep, hipMemcpyDeviceToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  std::swap(nb.p, rp_buf_.p);
+  std::swap(nb.n, rp_buf_.n);
+  rp_off_.erase(rp_off_.begin(), rp_off_.begin() + drop);
+  rp_hdr_.erase(rp_hdr_.begin(), rp_hdr_.begin() + drop);
+  for (auto& o : rp_off_) o -= (int64_t)cut;
+  rp_used_ = keep;
+  rp_positions_ = pos;
+}
+
+void Engine::replay_clear() {
+  rp_off_.clear();
+  rp_hdr_.clear();
+  rp_used_ = 0;
+  rp_positions_ = 0;
+}
+
+// every parameter of the selected network as one flat vector, in a fixed (layer, kind) order
+static void weight_keys(int tower, std::vector<std::pair<int, int>>& keys) {
+  for (int l = 0; l <= 2 * tower; ++l)
+    for (int k = 0; k < 7; ++k) keys.push_back({l, k});
+  for (int l : {AGZ_L_VALUE_CONV, AGZ_L_POLICY_CONV})
+    for (int k = 0; k < 7; ++k) keys.push_back({l, k});
+  for (int l : {AGZ_L_VALUE_FC1, AGZ_L_VALUE_FC2, AGZ_L_POLICY_FC})
+    for (int k = 0; k < 2; ++k) keys.push_back({l, k});
+}
+
+std::vector<float> Engine::weights_flat() {
+  std::vector<std::pair<int, int>> keys;
+  weight_keys(net().tower(), keys);
+  std::vector<float> w;
+  for (auto& lk : keys) {
+    const int64_t n = net().param_count(lk.first, lk.second);
+    const size_t at = w.size();
+    w.resize(at + (size_t)n);
+    net().get(lk.first, lk.second, w.data() + at, n);
+  }
+  return w;
+}
+
+void Engine::weights_set_flat(const std::vector<float>& w) {
+  std::vector<std::pair<int, int>> keys;
+  weight_keys(net().tower(), keys);
+  size_t at = 0;
+  for (auto& lk : keys) {
+    const int64_t n = net().param_count(lk.first, lk.second);
+    AGZ_REQUIRE(at + (size_t)n <= w.size(), AGZ_BAD_SHAPE, "flat weight vector too short");
+    net().set(lk.first, lk.second, w.data() + at, n);
+    at += (size_t)n;
+  }
+  AGZ_REQUIRE(at == w.size(), AGZ_BAD_SHAPE, "flat weight vector too long");
+}
+
+void Engine::replay_batch(const int64_t* game, const int32_t* ply, int B, float* feats, float* pi, float* z,
+                          bool out_is_device) {
+  AGZ_REQUIRE(B >= 0, AGZ_BAD_ARGUMENT, "negative batch");
+  if (B == 0) return;
+  AGZ_REQUIRE(game && ply && feats, AGZ_BAD_ARGUMENT, "null pointer");
+  std::vector<int64_t> off((size_t)B);
+  for (int b = 0; b < B; ++b) {
+    AGZ_REQUIRE(game[b] >= 0 && game[b] < (int64_t)rp_hdr_.size(), AGZ_BAD_ARGUMENT, "sample %d: game out of range", b);
+    AGZ_REQUIRE(ply[b] >= 0 && ply[b] < rp_hdr_[(size_t)game[b]].num_moves, AGZ_BAD_ARGUMENT,
+                "sample %d: ply outside the game (searches_pi has one entry per move played)", b);
+    off[b] = rp_off_[(size_t)game[b]];
+  }
+  const size_t per = (size_t)17 * V_.P;
+  s_i64a_.ensure((size_t)B);
+  s_i32a_.ensure((size_t)B);
+  s_boards_.ensure((size_t)B * 8 * V_.PP);
+  float *df = feats, *dp = pi, *dz = z;
+  if (!out_is_device) {
+    s_f32a_.ensure(per * (size_t)B);
+    s_f32b_.ensure((size_t)B * (V_.A + 1));
+    df = s_f32a_.p;
+    dp = pi ? s_f32b_.p : nullptr;
+    dz = z ? s_f32b_.p + (size_t)B * V_.A : nullptr;
+  }
+  AGZ_HIP(hipMemcpyAsync(s_i64a_.p, off.data(), sizeof(int64_t) * (size_t)B, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipMemcpyAsync(s_i32a_.p, ply, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_replay_arena_batch, dim3(B), dim3(kWave), 0, stream_, V_, (const uint8_t*)rp_buf_.p,
+                     (const int64_t*)s_i64a_.p, (const int32_t*)s_i32a_.p, s_boards_.p, df, dp, dz);
+  AGZ_HIP(hipGetLastError());
+  if (!out_is_device) {
+    AGZ_HIP(hipMemcpyAsync(feats, df, sizeof(float) * per * (size_t)B, hipMemcpyDeviceToHost, stream_));
+    if (pi) AGZ_HIP(hipMemcpyAsync(pi, dp, sizeof(float) * (size_t)B * V_.A, hipMemcpyDeviceToHost, stream_));
+    if (z) AGZ_HIP(hipMemcpyAsync(z, dz, sizeof(float) * (size_t)B, hipMemcpyDeviceToHost, stream_));
   }
   AGZ_HIP(hipStreamSynchronize(stream_));
 }

@@ -104,8 +104,17 @@ def cpu_baseline(N, tower, readouts, seconds):
     evals = L.or_player_evals(p)
     L.or_player_free(p)
     L.or_net_free(net)
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
     return {
-        "value": played / dt, "unit": "positions/s", "cores": cores, "kind": "port",
+        "value": played / dt, "unit": "positions/s", "cores": cores, "kind": "port", "cpu": model,
+        "host_threads_visible": os.cpu_count(), "threads_usable": avail,
         "sample": f"first {played} moves of one self-play game (GoEnv({N}), tower {tower}, {readouts} readouts, "
                   f"batches of 8, fp32 C network with OpenMP on {cores} threads), {evals} evals in {dt:.1f} s",
         "note": "reference (Julia/Flux) is not runnable here: no julia binary; CPU restatement timed",
@@ -191,6 +200,27 @@ def main():
     eng.profile_conv(False)
     s1 = eng.stats()
 
+    # The one exchange step of the path, outside the timed region: every rank's finished records
+    # are all-gathered into every rank's device replay arena by libagz itself (agz_allgather_records: RCCL over
+    # xGMI, device to device).  torch.distributed only carries the 128-byte RCCL unique id to the other ranks.
+    exchange = None
+    if dist is not None and not args.single_device_test:
+        try:
+            ids = [ag.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = eng.comm_create(rank, world, ids[0])
+            barrier()
+            e0 = time.perf_counter()
+            added = eng.allgather_records(comm)
+            eng.sync()
+            e1 = time.perf_counter()
+            exchange = {"collective": "agz_allgather_records (count exchange + padded ncclAllGather, device to device)",
+                        "games_in_arena": added, "positions_in_arena": eng.replay_positions(),
+                        "ms": 1e3 * (e1 - e0), "own_games": eng.records_count()}
+            eng.comm_destroy(comm)
+        except Exception as ex:      # the exchange leg must never take the self-play number down with it
+            exchange = {"error": str(ex)}
+
     elapsed = t1 - t0
     d = {k: s1[k] - s0[k] for k in ("positions", "evals", "duplicate_evals", "terminal_visits", "root_visits",
                                     "games_finished", "steps")}
@@ -210,9 +240,34 @@ def main():
         fpos = R * f_eval(N, tower)
         T = (N + 2) // 3
         f16 = args.precision == "f16"
-        wino_ratio = 1.0 if f16 else 25.0 * T * T / (81.0 * N * N) * 9.0   # executed / algorithmic multiplies of F(3x3,3x3)
+        wino_ratio = 1.0 if f16 else 25.0 * T * T / (9.0 * N * N)   # executed / algorithmic multiplies of F(3x3,3x3)
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = (None, None) if (f16 or N != 9) else pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256))
+        # The roofline object.  `achieved`/`frac` are what the MFMA pipe EXECUTES: Winograd F(3x3,3x3) needs 25
+        # multiplies per 3x3 output tile and (cin, cout) pair instead of 81, all of them still f32, so the
+        # honest fraction of the f32 MFMA peak is executed flops / time / peak (<= 1).  The rate in terms of the
+        # direct convolution's flops (SURVEY.md 8d's per-unit figure) is reported next to it as
+        # `achieved_algorithmic`; it may exceed the peak by up to the strength-reduction factor.
+        conv_s = conv_ms * 1e-3
+        alg_tf = conv_flop / conv_s / 1e12 if conv_ms > 0 else None
+        exe_tf = alg_tf * wino_ratio if alg_tf is not None else None
+        roofline = {
+            "bound": "mfma",
+            "kernel": "3x3 256->256 tower conv = k_conv3x3_f16 (implicit GEMM, v_mfma_f32_32x32x16_f16)" if f16 else
+                      "3x3 256->256 tower conv (Winograd F(3x3,3x3) on v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)",
+            "achieved": exe_tf, "peak": peak, "unit": "TFLOP/s",
+            "frac": exe_tf / peak if exe_tf is not None else None,
+            "achieved_algorithmic": alg_tf,
+            "algorithmic_over_executed": 1.0 / wino_ratio,
+            "note": "achieved = flops the MFMA pipe executes per launch / average launch time (HIP events on the engine's "
+                    "stream around every tower-conv launch of the timed region); achieved_algorithmic = 2*rows*9*256*256 "
+                    "per launch / the same time",
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": 2560.0 * conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256),
+            "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
+            "executed_flop_per_launch_avg": conv_flop * wino_ratio / max(conv_n, 1),
+            "algorithmic_flop_per_launch_avg": conv_flop / max(conv_n, 1),
+        }
         out = {
             "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)" + (" [fp16 tower]" if f16 else ""),
             "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -230,24 +285,12 @@ def main():
             "duplicate_evals": d["duplicate_evals"], "terminal_visits": d["terminal_visits"],
             "readout_positions_per_s": d["root_visits"] / R / elapsed,
             "games_finished": d["games_finished"],
-            "end_to_end_mfma_frac": value * fpos / (world * peak * 1e12),
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "3x3 256->256 tower conv = k_conv3x3_f16 (implicit GEMM, v_mfma_f32_32x32x16_f16)" if f16 else
-                          "3x3 256->256 tower conv = k_wino_in + k_wino_gemm (Winograd F(3x3,3x3), v_mfma_f32_32x32x2_f32)",
-                "note": "achieved = ALGORITHMIC flops of the direct convolution (2*rows*9*256*256 per launch) / launch time; "
-                        "Winograd executes 3.24x fewer multiplies, all in f32, so frac may exceed 1",
-                "achieved": conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
-                "peak": peak, "unit": "TFLOP/s",
-                "frac": (conv_flop / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
-                "flop_per_launch_avg": conv_flop / max(conv_n, 1),
-                # what the MFMA pipe actually executes: 25 multiplies per 3x3 output tile and (cin, cout)
-                "executed_flop_per_launch_avg": conv_flop * wino_ratio / max(conv_n, 1),
-                "executed_frac": (conv_flop * wino_ratio / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
-            },
+            "end_to_end_algorithmic_tflops": value * fpos / world / 1e12,          # positions/s x F_position
+            "end_to_end_executed_mfma_frac": value * fpos * wino_ratio / (world * peak * 1e12),
+            "roofline": roofline,
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, tower, R, args.cpu_baseline_seconds)

@@ -232,6 +232,54 @@ agz_status agz_replay_features(agz_engine* e, const int16_t* moves, int64_t nmov
                                const int32_t* game_offset, const int32_t* ply, int32_t B, float* out,
                                int32_t out_is_device);
 
+/* ---------------------------------------------------------------- replay arena + exchange -- */
+/* The replay buffer of train() (pos_buffer / pi_buffer / res_buffer, train.jl:47-66) as a device-resident
+ * arena of packed game records: games of EVERY rank, in arrival order, addressed by index 0..count-1.
+ * A (game, ply) pair is a training sample: position before move `ply` (rebuilt on the device by
+ * replay_position, board.jl:557-578), pi = searches_pi[ply], z = result (extract_data, mcts_play.jl:126-139). */
+/* append packed records ([header | moves | pis | qs] as written by agz_records_export_packed) from a host or
+ * device buffer, e.g. games loaded from disk or received by other means; added_out may be NULL */
+agz_status agz_replay_ingest_packed(agz_engine* e, const void* packed, int64_t nbytes, int32_t is_device,
+                                    int64_t* added_out);
+int64_t agz_replay_count(agz_engine* e);                 /* games in the arena                       */
+int64_t agz_replay_positions(agz_engine* e);             /* sum of num_moves = length(pos_buffer)    */
+agz_status agz_replay_header(agz_engine* e, int64_t k, agz_game_header* out);
+agz_status agz_replay_game(agz_engine* e, int64_t k, int16_t* moves, float* pis, float* qs);
+/* `shrink` (train.jl:52): forget the oldest games until at most max_positions positions remain */
+agz_status agz_replay_trim(agz_engine* e, int64_t max_positions);
+agz_status agz_replay_clear(agz_engine* e);
+/* get_replay_batch (train.jl:4-12) for B sampled (game, ply) pairs, ply < num_moves(game):
+ * feats float[B][N*N*17] (order of agz_features), pi float[B][A], z float[B]; pi / z may be NULL;
+ * the three outputs are host pointers, or device pointers when out_is_device != 0 */
+agz_status agz_replay_batch(agz_engine* e, const int64_t* game, const int32_t* ply, int32_t B, float* feats,
+                            float* pi, float* z, int32_t out_is_device);
+
+/* The one exchange step of the path: RCCL over xGMI, one rank per GPU.  Rank 0 calls
+ * agz_comm_unique_id and hands the 128 bytes to the other ranks by whatever means the host has (Julia:
+ * Distributed / a shared file; Python: torch.distributed / gloo); every rank then calls agz_comm_create with
+ * the engine that lives on its GPU.  RCCL is bound at run time (dlopen librccl.so.1); a missing library or a
+ * failing collective returns AGZ_RCCL_ERROR with the RCCL error string in agz_last_error. */
+#define AGZ_COMM_ID_BYTES 128
+typedef struct agz_comm agz_comm;
+agz_status agz_comm_unique_id(uint8_t* id_out /* [AGZ_COMM_ID_BYTES] */);
+agz_status agz_comm_create(agz_engine* e, int32_t rank, int32_t world, const uint8_t* id, agz_comm** out);
+void agz_comm_destroy(agz_comm* c);
+/* all-gather the finished records of every rank (what agz_records_* shows on each) into THIS rank's replay
+ * arena, rank 0's games first: count exchange + one padded ncclAllGather, device to device; the caller
+ * follows up with agz_records_clear.  comm == NULL: single-GPU run, files the engine's own records.
+ * added_out (may be NULL) = games appended.  Collective: every rank of the communicator must call it. */
+agz_status agz_allgather_records(agz_engine* e, agz_comm* comm, int64_t* added_out);
+/* overwrite every rank's weight replica with rank `root`'s parameters of the selected network (after a
+ * training step on one rank); nfloats_out may be NULL.  Collective. */
+agz_status agz_broadcast_weights(agz_engine* e, agz_comm* comm, int32_t root, int64_t* nfloats_out);
+
+/* ---------------------------------------------------------------- ABI self-description --- */
+/* sizeof and field offsets of the PODs above as this library was compiled, so that a host mirror (ctypes
+ * Structure, Julia struct) can be checked against them: name in {"agz_config", "agz_stats",
+ * "agz_game_header", "agz_position_info", "agz_node_info"}; out[0] = sizeof, out[1..n] = offsetof of the n
+ * fields in declaration order; returns n, or -1 for an unknown name / too small a buffer. */
+int32_t agz_abi_layout(const char* name, int32_t* out, int32_t cap);
+
 /* ---------------------------------------------------------------- single-tree compat ---- */
 /* The reference's MCTSPlayer / MCTSNode API on game slot g (tests drive these one call at a
  * time exactly like test/test_mcts.jl and test/test_mcts_player.jl).  Node handles are
