@@ -82,7 +82,7 @@ class Net {
   int bcap_ = 0;
   DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
   bool winograd_ = true;
-  DevBuf<float> d_uwino_, d_vimg_;        // transformed weights (stage images) / transformed activations
+  DevBuf<float> d_uwino_, d_vimg_, d_vimg2_;   // transformed weights (stage images) / transformed activations (ping-pong)
   int precision_ = 0;
   bool packed16_ = false;
   DevBuf<uint16_t> d_wi16_;               // fp16 tower weights as padded LDS tile images [layer][stage 72][256][40]
@@ -100,8 +100,13 @@ class Net {
 void wino_pack_weights(const ConvHost& c, float* out);
 size_t wino_weight_floats();
 size_t wino_v_floats(int bcap, int T);
-void launch_wino_conv(const float* x, float* vimg, const float* uimg, const float* scale, const float* shift,
-                      const float* res, float* y, const int* d_count, int bcap, int N, int relu, hipStream_t s);
+// x -> V (the 25 transformed planes as GEMM stage images); needed in front of the first Winograd layer, and
+// in front of every layer when the board's tiles do not pack into whole-board tile blocks (!wino_fusable)
+void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s);
+// V, U -> y (if y != NULL: affine, residual, ReLU applied) and / or the NEXT layer's V (if vnext != NULL)
+void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
+                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s);
+bool wino_fusable(int N);
 
 // fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged
 void conv16_pack_images(const ConvHost& c, uint16_t* out);

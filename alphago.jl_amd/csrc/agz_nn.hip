@@ -550,7 +550,10 @@ void Net::reserve(int bcap) {
   d_t_.alloc(rows * kC);
   d_vh_.alloc(rows);
   d_ph_.alloc(rows * 2);
-  if (tower_ > 0) d_vimg_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
+  if (tower_ > 0) {
+    d_vimg_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
+    if (wino_fusable(N_)) d_vimg2_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
+  }
   bcap_ = bcap;
 }
 
@@ -600,20 +603,43 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
     a = b;     // the heads read the f32 output of the last block
   } else {
     const size_t per = (size_t)kC * 9 * kC, uper = wino_weight_floats();
-    auto conv = [&](int l, const float* in, const float* res, float* out) {
-      timed([&] {
-        if (winograd_)
-          launch_wino_conv(in, d_vimg_.p, d_uwino_.p + uper * l, sc + (size_t)l * kC, sh + (size_t)l * kC, res, out,
+    if (winograd_ && wino_fusable(N_)) {
+      // Winograd with the input transform of layer l+1 fused into the GEMM of layer l: only the first layer needs
+      // k_wino_in; conv1 of a block leaves nothing but V in HBM, conv2 leaves the block output (the next residual,
+      // and the heads' input) and the next block's V
+      float *vcur = d_vimg_.p, *vnxt = d_vimg2_.p;
+      for (int blk = 0; blk < tower_; ++blk) {     // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32
+        const int l1 = 2 * blk, l2 = 2 * blk + 1;
+        const bool last = blk + 1 == tower_;
+        timed([&] {
+          if (blk == 0) launch_wino_in(a, vcur, d_count, bcap, N_, stream_);
+          launch_wino_gemm(vcur, d_uwino_.p + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, nullptr, vnxt,
                            d_count, bcap, N_, 1, stream_);
-        else
-          hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, in, d_wtower_.p + per * l,
-                             sc + (size_t)l * kC, sh + (size_t)l * kC, res, out, d_count, N_, 1);
-      });
-    };
-    for (int blk = 0; blk < tower_; ++blk) {       // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32
-      conv(2 * blk, a, nullptr, t);
-      conv(2 * blk + 1, t, a, b);
-      std::swap(a, b);
+        });
+        timed([&] {
+          launch_wino_gemm(vnxt, d_uwino_.p + uper * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, a, b,
+                           last ? nullptr : vcur, d_count, bcap, N_, 1, stream_);
+        });
+        std::swap(a, b);
+      }
+    } else {
+      auto conv = [&](int l, const float* in, const float* res, float* out) {
+        timed([&] {
+          if (winograd_) {
+            launch_wino_in(in, d_vimg_.p, d_count, bcap, N_, stream_);
+            launch_wino_gemm(d_vimg_.p, d_uwino_.p + uper * l, sc + (size_t)l * kC, sh + (size_t)l * kC, res, out, nullptr,
+                             d_count, bcap, N_, 1, stream_);
+          } else {
+            hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, in, d_wtower_.p + per * l,
+                               sc + (size_t)l * kC, sh + (size_t)l * kC, res, out, d_count, N_, 1);
+          }
+        });
+      };
+      for (int blk = 0; blk < tower_; ++blk) {
+        conv(2 * blk, a, nullptr, t);
+        conv(2 * blk + 1, t, a, b);
+        std::swap(a, b);
+      }
     }
   }
   const int hgrid = std::min(ceil_div((long)bcap * P_, 4), 256 * 16);
@@ -667,9 +693,14 @@ void Net::launch_tower_conv_once(const int* d_count, int bcap) {
   if (precision_ == 1)
     launch_conv16_dma(d_ha_.p, d_wi16_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, 0, d_ht_.p, 0, d_count, bcap, N_, 1,
                       stream_);
-  else if (winograd_)
-    launch_wino_conv(d_a_.p, d_vimg_.p, d_uwino_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, d_t_.p, d_count, bcap,
+  else if (winograd_ && wino_fusable(N_))     // a steady-state tower layer: residual in, y and the next V out
+    launch_wino_gemm(d_vimg_.p, d_uwino_.p, d_scale_.p + kC, d_shift_.p + kC, d_a_.p, d_t_.p, d_vimg2_.p, d_count, bcap,
                      N_, 1, stream_);
+  else if (winograd_) {
+    launch_wino_in(d_a_.p, d_vimg_.p, d_count, bcap, N_, stream_);
+    launch_wino_gemm(d_vimg_.p, d_uwino_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, d_t_.p, nullptr, d_count, bcap, N_, 1,
+                     stream_);
+  }
   else
   hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)d_a_.p,
                      d_wtower_.p, d_scale_.p + kC, d_shift_.p + kC, (const float*)nullptr, d_t_.p, d_count, N_, 1);

@@ -16,26 +16,25 @@
 //   (rows of B^T scaled to integers, the inverse scales folded into G, which is applied on the
 //   host in float64 at weight-pack time.)
 //
-// Two kernels per layer:
-//   k_wino_in    X[M][256] -> V, the 25 transformed planes, written directly in the LDS image
-//                order of the GEMM stages (HBM-bound: reads 1 KB, writes 2.9 KB per board point)
-//   k_wino_gemm  25 GEMMs  M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout]  on
-//                v_mfma_f32_32x32x2_f32, 64 tiles x 64 couts x 25 planes per workgroup: 410 KB of
-//                accumulators, i.e. the CU's whole 512 KB register file is the tile.  12 waves =
-//                4 quadrants (32 x 32) x 3 plane groups (9/8/8 planes, 144 accumulator VGPRs each).
-//                The inverse transform A^T M A is linear in the planes: every wave reduces its own
-//                planes to a partial 3x3 output, the partials meet through the (by then idle) stage
-//                buffers in a FIXED order, and bias+BatchNorm affine, residual add and ReLU follow in
-//                registers: M is never written to memory.
-// Stage = 4 input channels x {64 tiles + 64 couts} x 25 planes = 52 KB, triple-buffered in LDS and
-// filled by direct global->LDS DMA (global_load_lds_dwordx4), which is why V and U are stored in
-// HBM as ready-made, bank-swizzled stage images.  64x64 per workgroup gives 16 flop per DMA byte;
-// the L2->LDS path (~11 TB/s measured with the MFMAs compiled out) and the MFMA pipe are co-critical.
+// Kernels:
+//   k_wino_in     X[M][256] -> V, the 25 transformed planes, written directly in the LDS image order of the
+//                 GEMM stages (HBM-bound: reads 1 KB, writes 2.9 KB per board point).  Needed in front of the
+//                 FIRST tower layer only when tile blocks hold whole boards (N <= 12); every later layer's V
+//                 is emitted by the previous layer's GEMM epilogue.
+//   k_wino_gemm4  25 GEMMs  M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout]  on
+//                 v_mfma_f32_32x32x2_f32, 64 tiles x 64 couts x 25 planes per workgroup: 410 KB of accumulators,
+//                 i.e. the CU's whole 512 KB register file is the tile -- four waves, one per SIMD, 400
+//                 accumulator registers each.  Inverse transform, BatchNorm affine, residual, ReLU and the NEXT
+//                 layer's input transform follow in the epilogue: M is never written to memory.
+// Stage = 4 input channels x {64 tiles + 64 couts} x 25 planes = 52 KB, triple-buffered in LDS and filled by
+// direct global->LDS DMA (global_load_lds_dwordx4), which is why V and U are stored in HBM as ready-made,
+// bank-swizzled stage images.  64x64 per workgroup gives 16 flop per DMA byte.
 #include "agz_nn.h"
 
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace agz {
 
@@ -51,16 +50,32 @@ constexpr int A_STAGE = WPL * WT * 8;    // floats (26,624 B)
 constexpr int B_STAGE = WPL * WC * 8;
 constexpr int STAGE = A_STAGE + B_STAGE;  // 13,312 floats = 52 KB
 
-// A row of a stage image is 8 dwords = [plane 2q: 4 channels | plane 2q+1: 4 channels], i.e. four
-// 2-dword "pairs": logical pair = 2*(xi & 1) + h, h = which half of the 4 channels.  The 32 rows a
-// wave reads with one ds_read_b64 start on only 8 distinct banks (8 dwords * r mod 64), so the pairs
-// are rotated by f(row): rows r, r+8, r+16, r+24 (same bank mod 64, the 32-lane groups of
-// ds_read_b64) and rows r, r+4, r+8, r+12 (same bank mod 32, the 16-lane groups of the fused
-// ds_read2*_b64 forms hipcc may emit) all get distinct pair slots => conflict-free either way.
+// U stage image (weights): [plane pair q 13][cout 64][8 dwords]; a row = [plane 2q: 4 cins | plane 2q+1: 4 cins]
+// as four 2-dword pairs, logical pair = 2*(xi & 1) + h (h = which half of the 4 channels), rotated by f(row) so
+// that the 32 rows a wave reads with one ds_read_b64 (stride 8 dwords: only 8 distinct start banks) hit 64
+// distinct banks: rows r, r+8, r+16, r+24 get distinct pair slots.
 __host__ __device__ __forceinline__ int wino_rot(int row) { return ((row >> 2) + (row >> 4)) & 3; }
 __host__ __device__ __forceinline__ int wino_pair_pos(int row, int xi, int h) {
   return (2 * (xi & 1) + h + wino_rot(row)) & 3;
 }
+// V stage image (activations): [plane pair q 13][plane parity 2][tile row 64][4 dwords]; the 4 dwords of a row
+// are the plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1.  Row stride 4 dwords: rows r and
+// r + 16 start on the same bank and take different slots, so a 32-row ds_read_b64 is conflict-free -- and a
+// producer whose lane = tile row writes each 16-byte row whole, 64 lanes = 1 KB contiguous per store
+// instruction (the fused input transform of k_wino_gemm4; with 32-byte rows rotated by f(row) its stores were
+// 16-byte halves at 32-byte stride plus 24 selects per row, or 8-byte scatters 3.5x slower).
+__host__ __device__ __forceinline__ int wino_v_off(int xi, int row, int h) {      // dword offset inside a stage image
+  return (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4) + row * 4 + 2 * ((h + (row >> 4)) & 1);
+}
+
+// rows of a 64-row tile block that carry tiles: whole boards when a board's tiles pack into 64 rows with
+// <= 10 % waste (N <= 12: T*T = 1, 4, 9, 16 -> 64, 64, 63, 64 rows), else dense packing
+__host__ __device__ inline int wino_rows_per_block(int T) {
+  const int tt = T * T;
+  const int whole = (WT / tt) * tt;
+  return (tt <= WT && whole * 10 >= WT * 9) ? whole : WT;
+}
+__host__ __device__ inline bool wino_whole_boards(int T) { return wino_rows_per_block(T) % (T * T) == 0 && T * T <= WT; }
 
 // ------------------------------------------------------------------ input transform
 
@@ -72,35 +87,32 @@ __device__ __forceinline__ void bt5(float x0, float x1, float x2, float x3, floa
   r[4] = 2.f * x1 - x2 - 2.f * x3 + x4;
 }
 
-// grid = 2 x tile blocks (32-tile halves); 256 threads = 32 tiles x 8 channel pairs (= 4 consecutive
-// stages x 2 halves): the eight lanes of a tile read one 64-byte run of every patch point.  A pass
-// covers 16 channels = 4 stages; the transformed values go to an LDS copy of this half-block's part
-// of the four stage images (4 x 13 chunks of 32 rows x 32 B = 1 KB) and leave for HBM as whole
-// 1 KB runs, 16 B per lane -- written straight from registers they were 16-byte fragments spread
-// over four stage images, and the kernel sat at 3.8 TB/s.  Stage images are skewed by {0,4,16,20}
-// dwords in LDS: a ds_write_b64 is served 16 lanes (2 tiles x 8 lanes) at a time over 32 banks, and
-// with that skew the 16 lanes cover all 32 banks exactly once (PMC: SQ_LDS_BANK_CONFLICT 0; the
-// {0,4,32,36} skew that would suit a 64-bank / 32-lane model measured 40 % conflicted cycles).
-template <int TPB, bool NT>   // tiles per workgroup: 32 (8 lanes = 64 B per patch point) or 16 (16 lanes = one 128 B line)
+// grid = 2 x tile blocks (32-tile halves); 256 threads = 32 tiles x 8 channel pairs (= 4 consecutive stages x 2
+// halves): the eight lanes of a tile read one 64-byte run of every patch point.  A pass covers 16 channels = 4
+// stages; the transformed values go to an LDS copy of this half-block's part of the four stage images (4 x 26
+// chunks of 32 rows x 16 B) and leave for HBM as whole 512-byte runs, 16 B per lane.  The LDS copies of the four
+// stages are skewed by 8 dwords each: a ds_write_b64 is served 16 lanes (2 tiles x 8 lanes) at a time over 32
+// banks, and with that skew the 16 lanes cover all 32 banks exactly once.
+template <int TPB, bool NT>
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T) {
+  static_assert(TPB == 32, "the copy-out below moves 32-row chunks");
   constexpr int LPT = 256 / TPB;             // lanes per tile
   constexpr int SP = LPT / 2;                // stages per pass
-  constexpr int CH = TPB * 8;                // dwords per chunk (TPB rows of one row pair)
-  constexpr int IMG = 13 * CH + 64;          // LDS stride between the stage images of a pass
-  constexpr int CPR = 256 / (TPB * 2);       // chunks copied out per round
+  constexpr int CH = TPB * 4;                // dwords per chunk (TPB rows of one plane)
+  constexpr int IMG = 26 * CH + 8;           // LDS stride between the stage images of a pass (+8: the bank skew)
   __shared__ __attribute__((aligned(16))) float img[SP * IMG];
-  auto skew = [](int sl) { return (sl & 1) * 4 + (sl >> 1) * 16; };
   const int P = N * N, TT = T * T;
+  const int RPB = wino_rows_per_block(T);          // rows of a tile block that carry tiles (whole boards, N <= 12)
   const long Mt = (long)(*d_count) * TT;
   constexpr int PARTS = WT / TPB;
   const int tb = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
-  if ((long)tb * WT + part * TPB >= Mt) return;
+  if ((long)tb * RPB + part * TPB >= Mt) return;
   const int hs = threadIdx.x % LPT, h = hs & 1, sl = hs >> 1;
   const int tl = threadIdx.x / LPT;                 // tile within this part
   const int row = part * TPB + tl;                  // row of the 64-row stage image
-  const long tile = (long)tb * WT + row;
-  const bool live = tile < Mt;
+  const long tile = (long)tb * RPB + row;
+  const bool live = row < RPB && tile < Mt;
   const int b = live ? (int)(tile / TT) : 0, t = live ? (int)(tile % TT) : 0;
   const int ti = t / T, tj = t % T;
   int off[25];                                      // element offsets < 2^31 (8192 x 361 x 256 = 7.6e8)
@@ -112,12 +124,11 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
       const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
       off[u * 5 + v] = ok ? (b * P + pi + N * pj) * kC : -1;
     }
-  const int rot = wino_rot(row);
-  float* mine = img + sl * IMG + skew(sl) + tl * 8;
-  // the unused plane slot 25 (second half of pair 12) is copied out with the rest: keep it finite
-  *reinterpret_cast<float2*>(mine + 12 * CH + 2 * ((2 + h + rot) & 3)) = make_float2(0.f, 0.f);
+  float* mine = img + sl * IMG + tl * 4 + 2 * ((h + (row >> 4)) & 1);
+  // the unused plane slot 25 (chunk 25) is copied out with the rest: keep it finite
+  *reinterpret_cast<float2*>(mine + 25 * CH) = make_float2(0.f, 0.f);
   float* gdst = vimg + (long)tb * WNS * A_STAGE + part * CH;
-  const int cq = threadIdx.x / (TPB * 2), cl = threadIdx.x % (TPB * 2);
+  const int cq = threadIdx.x / TPB, cl = threadIdx.x % TPB;      // copy-out: 8 chunks per round, 32 lanes each
   for (int sg = 0; sg < WNS / SP; ++sg) {
     const int st = sg * SP + sl;
     float2 d[25];
@@ -143,25 +154,22 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
       bt5(tx[i * 5 + 0], tx[i * 5 + 1], tx[i * 5 + 2], tx[i * 5 + 3], tx[i * 5 + 4], rx);
       bt5(ty[i * 5 + 0], ty[i * 5 + 1], ty[i * 5 + 2], ty[i * 5 + 3], ty[i * 5 + 4], ry);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const int xi = i * 5 + j;
-        *reinterpret_cast<float2*>(mine + (xi >> 1) * CH + 2 * ((2 * (xi & 1) + h + rot) & 3)) = make_float2(rx[j], ry[j]);
-      }
+      for (int j = 0; j < 5; ++j) *reinterpret_cast<float2*>(mine + (i * 5 + j) * CH) = make_float2(rx[j], ry[j]);
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 13; ++r) {
-      const int c = r * CPR + cq, s4 = c / 13, q = c % 13;     // chunk c = (stage s4 of this pass, row pair q)
+      const int c = r * 8 + cq, s4 = c / 26, xi = c % 26;     // chunk c = (stage s4 of this pass, plane xi)
       typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const f32x4 v = *reinterpret_cast<const f32x4*>(img + s4 * IMG + skew(s4) + q * CH + cl * 4);
-      f32x4* gp = reinterpret_cast<f32x4*>(gdst + (long)(sg * SP + s4) * A_STAGE + q * (WT * 8) + cl * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(img + s4 * IMG + xi * CH + cl * 4);
+      f32x4* gp = reinterpret_cast<f32x4*>(gdst + (long)(sg * SP + s4) * A_STAGE + (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4) + cl * 4);
       if (NT) __builtin_nontemporal_store(v, gp);     // V is 2.8x the activations and is read back much later
       else *gp = v;
     }
   }
 }
 
-// ------------------------------------------------------------------ GEMM + output transform
+// ------------------------------------------------------------------ LDS-DMA helpers
 
 // 16 bytes per lane straight from global memory into LDS (wave-uniform LDS base in M0 + lane*16).
 // Issued through inline asm on purpose: hipcc cannot prove that the DMA target (the OTHER stage
@@ -179,262 +187,336 @@ __device__ __forceinline__ void glds16(const float* g, unsigned lds_byte_addr) {
       : "memory");
 }
 
-// Inverse-transform coefficients A^T (3x5)
-__device__ __forceinline__ constexpr float wino_at(int o, int i) {
-  return o == 0 ? (i < 4 ? 1.f : 0.f)
-       : o == 1 ? (i == 1 ? 1.f : i == 2 ? -1.f : i == 3 ? 2.f : 0.f)
-                : (i == 1 ? 1.f : i == 2 ? 1.f : i == 3 ? 4.f : i == 4 ? 1.f : 0.f);
+// SGPR base + per-lane 32-bit offset: no 64-bit VALU address arithmetic per piece
+__device__ __forceinline__ void glds16s(const float* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_addr) {
+  unsigned keep;
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_byte_off), "s"(gbase_uniform), "s"(lds_byte_addr) : "memory");
 }
 
-// grid = tile blocks x (256 / WC); 768 threads = 12 waves = 3 per SIMD.
-//   sp = wave & 3  -> which 32-tile x 32-cout quadrant of the 64 x 64 workgroup tile
-//   pg = wave >> 2 -> which third of the 25 transform planes (9 / 8 / 8) this wave accumulates
-// A wave therefore keeps 9 x 16 = 144 accumulator VGPRs and runs v_mfma_f32_32x32x2_f32 fed by two
-// ds_read_b64 per plane; the three plane groups of a quadrant land on the same SIMD, so every SIMD
-// owns 25 planes x 2 MFMAs x 64 cycles = 3200 MFMA-cycles per 4-channel stage.  The inverse
-// transform is linear in the planes: each wave reduces its own planes to a partial 3x3 output, the
-// partials of groups 1 and 2 cross to group 0 through the (by then idle) stage buffers in LDS.
-template <int DBG, int PG>
-__device__ __forceinline__ void wino_gemm_body(float (*lds)[STAGE], const float* __restrict__ asrc,
-                                               const float* __restrict__ bsrc, const float* __restrict__ scale,
-                                               const float* __restrict__ shift, const float* __restrict__ res,
-                                               float* __restrict__ y, long Mt, int N, int T, int relu, int tb,
-                                               int cb, int wave, int lane) {
-  constexpr int X0 = PG == 0 ? 0 : PG == 1 ? 9 : 17;     // first plane of this group
-  constexpr int NX = PG == 0 ? 9 : 8;
+// ------------------------------------------------------------------ GEMM + output transform + next input transform
+//
+// k_wino_gemm4: the same 64 tiles x 64 couts x 25 planes workgroup tile, held by FOUR waves -- one per SIMD,
+// each with all 25 planes of its 32 x 32 quadrant: 400 accumulator registers of the 512 a lone wave owns on
+// gfx950 (VGPR + AGPR are one file).  What that buys over round 1's 12-wave form (4 quadrants x 3 plane groups,
+// partial inverse transforms meeting through LDS in three barrier-separated rounds):
+//   * the inverse transform A^T M A happens entirely in one wave's registers -- no partial sums crossing LDS,
+//     no epilogue barriers -- so the stage buffers are free for something else the moment the K loop ends;
+//   * that something else is the NEXT layer's input transform: a workgroup owns WHOLE boards (63 tile rows =
+//     7 boards at 9x9), so after its epilogue every 5x5 input patch of its 64 output channels, halo included,
+//     is at hand.  The activations go to an LDS board image, and the same workgroup emits the next layer's V
+//     stage images (16 of the 64 stages: its 64 couts are the next layer's cins 64 cb .. 64 cb + 63) straight
+//     to HBM.  k_wino_in -- a separate, HBM-bound pass with the MFMA pipe idle, 20 % of a step -- disappears
+//     from every layer but the first, and y itself is only written where a residual or the heads need it;
+//   * a v_mfma_f32_32x32x2_f32 keeps its SIMD's matrix pipe busy for 64 cycles, i.e. ~16 issue slots: the two
+//     ds_read_b64 of a plane and the occasional LDS-DMA instruction fit between two MFMAs of ONE wave, so
+//     there is nothing for co-resident waves to hide and nothing for them to contend for.
+// K loop: operands are read 4 planes (>= 256 MFMA cycles) ahead through a ring of 5 register pairs; the stage
+// barrier sits in the READ stream (before the first read of the next stage, i.e. 4 planes before the stage's
+// last MFMA), so the MFMAs of planes 21..24 cover the barrier and the first LDS latencies of the next stage.
+constexpr int IMG_STRIDE = 68;    // floats per board point of the LDS board image: 16-B aligned rows, and
+                                  // 4*pt + c (mod 64) spreads the tiles of a wave over the banks
+
+// MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
+// X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
+//   1 = K loop only; 2 = no epilogue 2; 3 = epilogue 2 without its global stores; 4 = no DMA after the prologue;
+//   5 = no MFMA; 6 = no LDS operand reads
+template <int MODE, int X = 0>
+__global__ __launch_bounds__(256, 1) void k_wino_gemm4(
+    const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
+  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
   const int P = N * N, TT = T * T;
-  const int sp = wave & 3, wm = sp & 1, wn = sp >> 1;
+  const int RPB = wino_rows_per_block(T);
+  const long Mt = (long)(*d_count) * TT;
+  // workgroup -> (tile block, cout block): see k_wino_gemm (U of two cout blocks stays L2-resident per XCD,
+  // the two cout blocks of a tile block are neighbours on one XCD and share its V slab)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, jb = bid >> 3;
+  const int cb = 2 * (xcd & 1) + (jb & 1);
+  const int tb = (xcd >> 1) + 4 * (jb >> 1);
+  if ((long)tb * RPB >= Mt) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0][0];
+  const float* asrc = vimg + (long)tb * WNS * A_STAGE;
+  const float* bsrc = uimg + (long)cb * WNS * B_STAGE;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0];
 
-  // a stage is 52 chunks of 1 KB (64 lanes x 16 B): chunks 0..25 from V, 26..51 from U
-  auto issue = [&](int st, int buf) {
-    const float* a = asrc + (long)st * A_STAGE;
-    const float* b = bsrc + (long)st * B_STAGE;
-    for (int c = wave; c < 52; c += 12) {
-      if ((DBG == 7 && c >= 26) || (DBG == 8 && c < 26)) continue;     // timing: only the V / only the U stream
-      const float* g = c < 26 ? a + c * 256 : b + (c - 26) * 256;
-      glds16(g + lane * 4, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
-    }
-  };
-
-  // the j-th chunk of this wave (c = wave + 12 j).  The five DMA instructions of a stage are spread
-  // between the MFMAs of the K loop: issued in one block at the top of a stage -- by all twelve
-  // waves at once, straight after the barrier -- their ~90 scalar/VALU/VMEM instructions per wave
-  // kept every wave of a SIMD off the MFMA pipe at the same time (measured: +0.6 ms per layer even
-  // with the loads never waited for and the MFMAs fed from constants).
+  // a stage is 52 chunks of 1 KB: 0..25 from V, 26..51 from U; wave w moves the 13 consecutive chunks 13 w ..
+  // (waves 0, 1: V; waves 2, 3: U) with a wave-uniform base in SGPRs and a 32-bit lane offset: per-lane 64-bit
+  // address arithmetic in front of every piece cost 8 % of the K loop (2.10 -> 1.95 ms per layer)
   auto dma = [&](int st, int buf, int j) {
-    const int c = wave + 12 * j;
-    if (c >= 52) return;
-    if ((DBG == 7 && c >= 26) || (DBG == 8 && c < 26)) return;       // timing: only the V / only the U stream
-    const float* g = c < 26 ? asrc + (long)st * A_STAGE + c * 256 : bsrc + (long)st * B_STAGE + (c - 26) * 256;
-    glds16(g + lane * 4, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
+    const int c = 13 * wave + j;
+    const float* g = wave < 2 ? asrc + (long)st * A_STAGE + c * 256 : bsrc + (long)st * B_STAGE + (c - 26) * 256;
+    glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
   };
 
-  f32x16 acc[NX];
+  f32x16 acc[WXI];
 #pragma unroll
-  for (int i = 0; i < NX; ++i)
+  for (int i = 0; i < WXI; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
-  const int arot = wino_rot(arow), brot = wino_rot(brow);
-  const int abase = arow * 8, bbase = A_STAGE + brow * 8;
-
-  // Three stage buffers, two stages of DMA in flight: the L2->LDS path is latency-bound at one
-  // stage in flight (measured ~35 GB/s per CU), so the wait before a barrier is a COUNTED vmcnt
-  // that leaves the newest stage's requests (5 per wave for waves 0-3, 4 for the rest) outstanding.
-  const bool five = wave < 4;
-  issue(0, 0);
-  if (DBG != 1 && DBG != 3 && DBG != 4 && DBG != 5) issue(1, 1);
-  if (DBG == 1 || DBG == 3 || DBG == 4 || DBG == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __syncthreads();
-  // Software-pipelined across the barrier.  Reading a stage's operands only after the barrier that
-  // publishes it left the LDS latency -- ~600 cycles under DMA write traffic -- exposed once per
-  // 3200-cycle stage (0.6 ms of 2.6 per layer).  So the LAST planes of every stage (NH of them) are
-  // "held back": their operands are read before the barrier, their MFMAs are issued after it, right
-  // behind the first reads of the next stage, whose latency they cover.  The 8-plane groups hold two
-  // planes (8 VGPRs); the 9-plane group has no register to spare (144 accumulators) and holds none --
-  // its reads hide behind the held MFMAs of the two other waves of its SIMD.
-  constexpr int NH = PG == 0 ? 0 : 2, NS = NX - NH;
-  float2 aH[NH + 1], bH[NH + 1];
-  auto load = [&](const float* L, int k, float2& a, float2& b) {
-    const int xi = X0 + k;
-    const int lp = 2 * (xi & 1) + hi;
-    a = *reinterpret_cast<const float2*>(L + abase + (xi >> 1) * WT * 8 + 2 * ((lp + arot) & 3));
-    b = *reinterpret_cast<const float2*>(L + bbase + (xi >> 1) * WC * 8 + 2 * ((lp + brot) & 3));
-    if (DBG == 4 || DBG == 5 || DBG == 9) { a = make_float2(1.f, 1.f); b = make_float2(2.f, (float)lane); }   // timing: no LDS reads
+  const int brot = wino_rot(brow);
+  // per-lane float offsets of the even / odd planes' pair slots; plane xi adds (xi >> 1) * 512 floats
+  const int aoff[2] = {wino_v_off(0, arow, hi), wino_v_off(1, arow, hi)};
+  const int boff[2] = {A_STAGE + brow * 8 + 2 * ((hi + brot) & 3), A_STAGE + brow * 8 + 2 * ((2 + hi + brot) & 3)};
+  constexpr int LA = 4, RING = LA + 1;     // 25 % RING == 0: ring slots are compile-time within a stage
+  float2 ra[RING], rb[RING];
+  auto load = [&](const float* L, int xi, float2& a, float2& b) {
+    if (X == 6) { a = make_float2(1.f, (float)lane); b = make_float2(2.f, (float)xi); return; }
+    a = *reinterpret_cast<const float2*>(L + aoff[xi & 1] + (xi >> 1) * (WT * 8));
+    b = *reinterpret_cast<const float2*>(L + boff[xi & 1] + (xi >> 1) * (WC * 8));
   };
+
+  // 400 accumulators: hipcc gives EVERY MFMA of a kernel the same accumulator register class, so beyond 256 it
+  // shuttles tuples between the two halves of the file around every MFMA (308 v_accvgpr moves and 24 scratch
+  // accesses per stage when left alone).  The first NAG planes therefore use the builtin (accumulators in
+  // AGPRs: 16 x 16 = the whole accumulator half) and the other 9 an asm MFMA whose "+v" constraint keeps
+  // their 144 registers in the VGPR half.  Wait states (cdna_hip_programming.md 5.7): an accumulate chain
+  // needs none; the leading s_nop 1 covers a compiler v_mov into an A/B operand; the D -> VALU distance is
+  // padded once, after the K loop.
+  constexpr int NAG = 16;
   auto mma = [&](int k, const float2& a, const float2& b) {
-    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[k], 0, 0, 0);
-    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
-  };
-  int buf = 0;
-  for (int st = 0; st < WNS; ++st) {
-    const int nbuf = buf == 0 ? 2 : buf - 1;            // (st + 2) % 3
-    const bool more = st + 2 < WNS && DBG != 1 && DBG != 3 && DBG != 4 && DBG != 5;
-    const float* L = lds[buf];
-    if (DBG == 2) {
-      if (more) issue(st + 2, nbuf);
+    if (k < NAG) {
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[k], 0, 0, 0);
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
     } else {
-      // operands are read one plane ahead (two register pairs, alternating); the DMA instruction of
-      // a slot sits between that read and the MFMAs it will feed
-      constexpr int LA = 1;   // planes read ahead of the MFMAs (register ring of LA + 1; 2 was measured slower)
-      float2 ra[LA + 1], rb[LA + 1];
-#pragma unroll
-      for (int k = 0; k < LA; ++k) load(L, k, ra[k], rb[k]);
-      if (st > 0) {
-#pragma unroll
-        for (int k = 0; k < NH; ++k) mma(NS + k, aH[k], bH[k]);     // the previous stage's held planes
-      }
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        if (k + LA < NS) load(L, k + LA, ra[(k + LA) % (LA + 1)], rb[(k + LA) % (LA + 1)]);
-        if (k < 5) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) dma(st + 2, nbuf, k);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        mma(k, ra[k % (LA + 1)], rb[k % (LA + 1)]);
-      }
-#pragma unroll
-      for (int k = 0; k < NH; ++k) load(L, NS + k, aH[k], bH[k]);
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\tv_mfma_f32_32x32x2_f32 %0, %3, %4, %0"
+                   : "+v"(acc[k])
+                   : "v"(a.x), "v"(b.x), "v"(a.y), "v"(b.y));
     }
-    // this wave's share of stage st+1 has landed (stage st+2 may still be in flight) ...  (hipcc puts
-    // an s_waitcnt lgkmcnt(0) in front of the barrier itself: every LDS read of stage st has
-    // returned before any wave can overwrite that buffer with the DMA of stage st+3)
-    if (DBG == 6 || DBG == 7 || DBG == 8 || DBG == 9) { if (st == WNS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // timing: never wait for the DMA
-    else if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if (DBG != 3) __syncthreads();                      // ... and so has everybody else's
-    buf = buf == 2 ? 0 : buf + 1;
-  }
-  if (DBG != 2) {
-#pragma unroll
-    for (int k = 0; k < NH; ++k) mma(NS + k, aH[k], bH[k]);
-  }
+  };
 
-  // epilogue.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e&3) + 8*(e>>2) + 4*(lane>>5),
-  // so the planes of one (tile, cout) pair sit in the same lane and register index e of the three
-  // plane-group waves of a quadrant.  Each wave reduces ITS planes to a partial 3x3 output per e;
-  // the 16 register indices are owned 6 / 5 / 5 by the three groups, partials for foreign e's cross
-  // through LDS (the stage buffers are idle now), and every wave finalises its own e's -- affine,
-  // residual, ReLU, store -- so all 12 waves share the memory traffic.  Three rounds of 2+2+2 e's
-  // keep the exchange at 110 KB.
-  if (DBG == 5) {   // timing: K loop only -- keep the accumulators alive, skip the epilogue
+#pragma unroll
+  for (int j = 0; j < 13; ++j) dma(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < 13; ++j) dma(1, 1, j);
+  asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < LA; ++k) load(lds, k, ra[k], rb[k]);
+
+  // One stage.  MORE: stage st+2 exists and is fetched during this stage; NEXT: stage st+1 exists.  Both are
+  // compile-time so that the 62 full stages run a branch-free body (the two tail stages are separate code).
+  int buf = 0;
+  auto stage = [&](int st, auto more_c, auto next_c) {
+    constexpr bool more = decltype(more_c)::value, next = decltype(next_c)::value;
+    const int nbuf = buf == 2 ? 0 : buf + 1;          // stage st+1
+    const int dbuf = buf == 0 ? 2 : buf - 1;          // stage st+2 (= the buffer stage st-1 was read from)
+    const float* L = lds + buf * STAGE;
+    const float* Ln = lds + nbuf * STAGE;
+#pragma unroll
+    for (int k = 0; k < WXI; ++k) {
+      const int t = k + LA;
+      if (t == WXI && next) {
+        // everything this wave owes to stage st+1 has landed (its share of stage st+2 issued so far, 11 of 13,
+        // may still be in flight); hipcc adds lgkmcnt(0) in front of the barrier: all reads of stage st are back
+        if (more && X != 4) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (t < WXI) load(L, t, ra[t % RING], rb[t % RING]);
+      else if (next) load(Ln, t - WXI, ra[t % RING], rb[t % RING]);
+      if (more && (k & 1) == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (X != 4) dma(st + 2, dbuf, k >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (X != 5) mma(k, ra[k % RING], rb[k % RING]);
+    }
+    buf = nbuf;
+  };
+  for (int st = 0; st < WNS - 2; ++st) stage(st, std::true_type{}, std::true_type{});
+  stage(WNS - 2, std::false_type{}, std::true_type{});
+  stage(WNS - 1, std::false_type{}, std::false_type{});
+
+  // the asm MFMAs' D registers -> VALU readers below: 18 wait states.  The pad must NAME those registers, or the
+  // scheduler is free to lift a register-only VALU read of them above it (seen: 4e-4 errors on some lanes)
+  static_assert(NAG == 16 && WXI == 25, "the pad below lists accumulators 16..24");
+  asm volatile("s_nop 15\n\ts_nop 15"
+               : "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]),
+                 "+v"(acc[23]), "+v"(acc[24]));
+  if (X == 1) {
     float keep = 0.f;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) keep += acc[k][0] + acc[k][15];
+    for (int k = 0; k < WXI; ++k) keep += acc[k][0] + acc[k][15];
     if (keep == 123.456f) y[0] = keep;
     return;
   }
-  float* xch = &lds[0][0];   // [owner pg][source slot 0..1][sp][ei 0..1][9][64 lanes]
-  const int co = cb * WC + wn * 32 + l31;
-  const float sc = scale[co], sh = shift[co];
-  auto partial = [&](int e, float* out) {   // A^T M A restricted to this wave's planes
-#pragma unroll
-    for (int oi = 0; oi < 3; ++oi)
-#pragma unroll
-      for (int oj = 0; oj < 3; ++oj) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-          const int xi = X0 + k, i = xi / 5, j = xi % 5;
-          const float c = wino_at(oi, i) * wino_at(oj, j);
-          if (c != 0.f) v += c * acc[k][e];
-        }
-        out[oi * 3 + oj] = v;
-      }
-  };
-#pragma unroll
-  for (int rd = 0; rd < 3; ++rd) {
-    // e's of this round: owner 0 -> {2rd, 2rd+1}; owner 1 -> {6+2rd, 7+2rd} (rd<2) or {10}; owner 2 -> {11+2rd, 12+2rd} or {15}
-    float own[2][9];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int ne = (q == 0 || rd < 2) ? 2 : 1;
-#pragma unroll
-      for (int ei = 0; ei < 2; ++ei) {
-        if (ei >= ne) continue;
-        const int e = (q == 0 ? 0 : q == 1 ? 6 : 11) + 2 * rd + ei;
-        float part[9];
-        partial(e, part);
-        if (q == PG) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) own[ei][k] = part[k];
-        } else {
-          const int slot = PG < q ? PG : PG - 1;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) xch[((((q * 2 + slot) * 4 + sp) * 2 + ei) * 9 + k) * 64 + lane] = part[k];
-        }
-      }
-    }
-    __syncthreads();
-    {
-      const int ne = (PG == 0 || rd < 2) ? 2 : 1;
-#pragma unroll
-      for (int ei = 0; ei < 2; ++ei) {
-        if (ei >= ne) continue;
-        const int e = (PG == 0 ? 0 : PG == 1 ? 6 : 11) + 2 * rd + ei;
-        const long tile = (long)tb * WT + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        if (tile >= Mt) continue;
-        const int b = (int)(tile / TT), t = (int)(tile % TT);
-        const int ti = t / T, tj = t % T;
-        long mrow[9];
-        float rv[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {   // nine residual loads issued back to back: one wait, not nine
-          const int pi = 3 * ti + k / 3, pj = 3 * tj + k % 3;
-          mrow[k] = (pi < N && pj < N) ? ((long)b * P + pi + (long)N * pj) * kC + co : -1;
-          rv[k] = (res && mrow[k] >= 0) ? res[mrow[k]] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          if (mrow[k] < 0) continue;
-          // fixed association (group0 + group1) + group2 whoever owns e: a position's result must
-          // not depend on which register index -- i.e. which batch row -- it happens to land on
-          const float x0 = xch[((((PG * 2 + 0) * 4 + sp) * 2 + ei) * 9 + k) * 64 + lane];
-          const float x1 = xch[((((PG * 2 + 1) * 4 + sp) * 2 + ei) * 9 + k) * 64 + lane];
-          const float yy = PG == 0 ? (own[ei][k] + x0) + x1 : PG == 1 ? (x0 + own[ei][k]) + x1 : (x0 + x1) + own[ei][k];
-          float v = yy * sc + sh + rv[k];
-          if (relu) v = fmaxf(v, 0.f);
-          y[mrow[k]] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
 
-template <int DBG>   // timing experiments only: 0 = product; 1 = no DMA after stage 0; 2 = no MFMA; 3 = 1 + no barriers; 4 = 1 + no LDS reads
-__global__ __launch_bounds__(768, 3) void k_wino_gemm(
-    const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-    const int* __restrict__ d_count, int N, int T, int relu) {
-  __shared__ __attribute__((aligned(16))) float lds[3][STAGE];
-  const long Mt = (long)(*d_count) * T * T;
-  // Workgroup -> (tile block, cout block) placement for the per-XCD L2 (4 MB, block b runs on XCD b % 8):
-  //   * even XCDs work on cout blocks {0,1}, odd XCDs on {2,3}: the transformed weights an XCD streams
-  //     over and over are 2 x 1.6 MB and stay L2-resident (with all four blocks per XCD the 6.5 MB
-  //     cyclic stream thrashed the L2 and U came from MALL/HBM: 7.5 GB per layer);
-  //   * the two cout blocks of a tile block are adjacent workgroups of one XCD and share the L2 copy
-  //     of that tile block's V slab, which is fetched from HBM by two XCDs (3.9 GB instead of 2).
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, j = bid >> 3;
-  const int cb = 2 * (xcd & 1) + (j & 1);
-  const int tb = (xcd >> 1) + 4 * (j >> 1);
-  if ((long)tb * WT >= Mt) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR)
-  const float* asrc = vimg + (long)tb * WNS * A_STAGE;
-  const float* bsrc = uimg + (long)cb * WNS * B_STAGE;
-  const int pg = wave >> 2;
-  if (pg == 0) wino_gemm_body<DBG, 0>(lds, asrc, bsrc, scale, shift, res, y, Mt, N, T, relu, tb, cb, wave, lane);
-  else if (pg == 1) wino_gemm_body<DBG, 1>(lds, asrc, bsrc, scale, shift, res, y, Mt, N, T, relu, tb, cb, wave, lane);
-  else wino_gemm_body<DBG, 2>(lds, asrc, bsrc, scale, shift, res, y, Mt, N, T, relu, tb, cb, wave, lane);
+  // ---- epilogue.  The stage buffers are dead once every wave has left the K loop; they become
+  //   img   [64 tile rows][9 outputs][IMG_STRIDE]  this workgroup's 64 x 64 x 9 activations (channel fastest)
+  //   ptab  [64 x 9] element offset of output (row, k) in y / res, or -1 (outside the board / dead row)
+  // Three phases, each a flat loop with every memory operation of the phase in flight at once -- a lone wave
+  // per SIMD has nobody to hide a load -> use round trip behind:
+  //   1   inverse transform A^T M A + BatchNorm affine in registers -> img            (no global memory)
+  //   1b  img (+ residual) -> ReLU -> y and back to img: 256-byte runs per output point, 16 B per lane;
+  //       skipped when there is neither a residual nor a y to write (conv1 of a block: ReLU happens in 1)
+  //   2   next layer's input transform V = B^T d B from img -> HBM stage images   (MODE & 2)
+  __syncthreads();
+  float* img = lds;
+  int* ptab = reinterpret_cast<int*>(lds + WT * 9 * IMG_STRIDE);
+  static_assert(WT * 9 * IMG_STRIDE + WT * 9 <= 3 * STAGE, "tile image + point table exceed the stage buffers");
+  const bool pass1b = (MODE & 1) || res != nullptr;
+  for (int idx = tid; idx < WT * 9; idx += 256) {
+    const int row = idx / 9, k = idx % 9;
+    const long tile = (long)tb * RPB + row;
+    int off = -1;
+    if (row < RPB && tile < Mt) {
+      const int b = (int)(tile / TT), t = (int)(tile % TT);
+      const int pi = 3 * (t / T) + k / 3, pj = 3 * (t % T) + k % 3;
+      if (pi < N && pj < N) off = (b * P + pi + N * pj) * kC + cb * WC;      // < 2^31: 8192 x 361 x 256 = 7.6e8
+    }
+    ptab[idx] = off;
+  }
+  {
+    // phase 1.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    const int col = wn * 32 + l31;
+    const float sc = scale[cb * WC + col], sh = shift[cb * WC + col];
+    const bool relu_now = relu && !pass1b;
+    // whole 16-register tuples at a time (element e of a tuple = tile row e of the C/D map): extracting single
+    // elements of AGPR-resident tuples made hipcc copy entire tuples back and forth (330 instructions per e)
+    f32x16 o[9];
+    {
+      f32x16 tmp[3][5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const f32x16 m0 = acc[0 * 5 + j], m1 = acc[1 * 5 + j], m2 = acc[2 * 5 + j], m3 = acc[3 * 5 + j], m4 = acc[4 * 5 + j];
+        tmp[0][j] = ((m0 + m1) + m2) + m3;
+        tmp[1][j] = (m1 - m2) + 2.f * m3;
+        tmp[2][j] = ((m1 + m2) + 4.f * m3) + m4;
+        __builtin_amdgcn_sched_barrier(0);       // a column at a time: its five accumulators die here
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        o[i * 3 + 0] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) + tmp[i][3];
+        o[i * 3 + 1] = (tmp[i][1] - tmp[i][2]) + 2.f * tmp[i][3];
+        o[i * 3 + 2] = ((tmp[i][1] + tmp[i][2]) + 4.f * tmp[i][3]) + tmp[i][4];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      float* dst = img + row * 9 * IMG_STRIDE + col;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        float v = o[k][e] * sc + sh;
+        if (relu_now) v = fmaxf(v, 0.f);
+        dst[k * IMG_STRIDE] = v;
+      }
+    }
+  }
+  __syncthreads();
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  if (pass1b) {
+    // phase 1b: element = (row, k, 4 channels); 16 consecutive lanes cover the 256 contiguous bytes of one point
+    constexpr int PER = WT * 9 * (WC / 4) / 256;      // 36 per thread
+    f32x4 rv[PER];
+    int offs[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + 256 * i;
+      offs[i] = ptab[idx >> 4];
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rv[i] = (res && offs[i] >= 0) ? *reinterpret_cast<const f32x4*>(res + offs[i] + 4 * (idx & 15)) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + 256 * i;
+      if (offs[i] < 0) continue;
+      f32x4* ip = reinterpret_cast<f32x4*>(img + (idx >> 4) * IMG_STRIDE + 4 * (idx & 15));
+      f32x4 v = *ip + rv[i];
+      if (relu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+      }
+      if (MODE & 1) *reinterpret_cast<f32x4*>(y + offs[i] + 4 * (idx & 15)) = v;
+      if (MODE & 2) *ip = v;
+    }
+    if (MODE & 2) __syncthreads();
+  }
+  if (!(MODE & 2) || X == 2) return;
+
+  // ---- phase 2: the next layer's input transform for this workgroup's 64 channels (= stages 16 cb .. 16 cb + 15
+  // of the next layer's K loop).  Task = (tile row, stage): lane = row, so that the 64 lanes of a wave fill 64
+  // consecutive 32-byte rows of a stage image; wave w takes stages w, w+4, w+8, w+12.
+  {
+    const int row = lane;
+    const long tile = (long)tb * RPB + row;
+    const bool live = row < RPB && tile < Mt;
+    const int t = live ? (int)(tile % TT) : 0, lb = row / TT;
+    const int ti = t / T, tj = t % T;
+    int poff[25];
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+      for (int v = 0; v < 5; ++v) {
+        const int pi = 3 * ti - 1 + u, pj = 3 * tj - 1 + v;
+        const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
+        // the point lives in tile (pi / 3, pj / 3) of the same board, output k = (pi % 3) * 3 + pj % 3
+        poff[u * 5 + v] = ok ? ((lb * TT + (pi / 3) * T + pj / 3) * 9 + (pi % 3) * 3 + pj % 3) * IMG_STRIDE : -1;
+      }
+    // a V image row is one plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1 (wino_v_off)
+    const bool swap = (row >> 4) & 1;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int sl = wave; sl < WC / WK; sl += 4) {
+      f32x4 d[25];
+#pragma unroll
+      for (int q = 0; q < 25; ++q) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + poff[q] + sl * WK) : z;
+      }
+      float* g = vnext + ((long)tb * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
+      // B^T d B on channel PAIRS (v_pk_*_f32: two channels per VALU instruction; no MFMA runs beside this)
+      auto bt5p = [](f32x2 x0, f32x2 x1, f32x2 x2, f32x2 x3, f32x2 x4, f32x2* r) {
+        r[0] = 2.f * x0 - x1 - 2.f * x2 + x3;
+        r[1] = 2.f * x1 + x2 - x3;
+        r[2] = -2.f * x1 + 3.f * x2 - x3;
+        r[3] = x3 - x1;
+        r[4] = 2.f * x1 - x2 - 2.f * x3 + x4;
+      };
+      f32x2 vv[25][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x2 tx[25];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+          f32x2 r[5], c[5];
+#pragma unroll
+          for (int u = 0; u < 5; ++u) c[u] = (f32x2){d[u * 5 + v][2 * h], d[u * 5 + v][2 * h + 1]};
+          bt5p(c[0], c[1], c[2], c[3], c[4], r);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) tx[i * 5 + v] = r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          f32x2 r[5];
+          bt5p(tx[i * 5 + 0], tx[i * 5 + 1], tx[i * 5 + 2], tx[i * 5 + 3], tx[i * 5 + 4], r);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) vv[i * 5 + j][h] = r[j];
+        }
+      }
+#pragma unroll
+      for (int xi = 0; xi < 26; ++xi) {
+        const f32x2 z2 = {0.f, 0.f};
+        const f32x2 p0 = xi < 25 ? vv[xi < 25 ? xi : 0][0] : z2, p1 = xi < 25 ? vv[xi < 25 ? xi : 0][1] : z2;
+        const f32x2 lo = swap ? p1 : p0, hi2 = swap ? p0 : p1;
+        const f32x4 v4 = {lo[0], lo[1], hi2[0], hi2[1]};
+        f32x4* gp = reinterpret_cast<f32x4*>(g + (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4));
+        if (X == 3) {
+          if (v4[0] + v4[3] == 123.456f) *gp = v4;
+          continue;
+        }
+        __builtin_nontemporal_store(v4, gp);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -466,21 +548,43 @@ void wino_pack_weights(const ConvHost& c, float* out) {
 }
 
 size_t wino_weight_floats() { return (size_t)(kC / WC) * WNS * B_STAGE; }
-size_t wino_v_floats(int bcap, int T) {
-  const long blocks = ((long)bcap * T * T + WT - 1) / WT;
-  return (size_t)blocks * WNS * A_STAGE;
+static long wino_blocks(int bcap, int T) {
+  const long rpb = wino_rows_per_block(T);
+  return ((long)bcap * T * T + rpb - 1) / rpb;
+}
+size_t wino_v_floats(int bcap, int T) { return (size_t)wino_blocks(bcap, T) * WNS * A_STAGE; }
+bool wino_fusable(int N) { return wino_whole_boards((N + 2) / 3); }
+
+void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s) {
+  const int T = (N + 2) / 3;
+  const int blocks = (int)wino_blocks(bcap, T);
+  hipLaunchKernelGGL((k_wino_in<32, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
 }
 
-void launch_wino_conv(const float* x, float* vimg, const float* uimg, const float* scale, const float* shift,
-                      const float* res, float* y, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
+// y == nullptr: the activations are not needed in HBM (only their transform is); vnext == nullptr: no next
+// Winograd layer (or a board size whose tile blocks do not hold whole boards: wino_fusable(N) is false)
+void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
+                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
   const int T = (N + 2) / 3;
-  const int blocks = (int)(((long)bcap * T * T + WT - 1) / WT);
-  hipLaunchKernelGGL((k_wino_in<32, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
-  static const int dbg = getenv("AGZ_WINO_DEBUG") ? atoi(getenv("AGZ_WINO_DEBUG")) : 0;   // timing experiments only
-  auto kern = dbg == 1 ? k_wino_gemm<1> : dbg == 2 ? k_wino_gemm<2> : dbg == 3 ? k_wino_gemm<3> : dbg == 4 ? k_wino_gemm<4> : dbg == 5 ? k_wino_gemm<5> : dbg == 6 ? k_wino_gemm<6> : dbg == 7 ? k_wino_gemm<7> : dbg == 8 ? k_wino_gemm<8> : dbg == 9 ? k_wino_gemm<9> : k_wino_gemm<0>;
-  const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm
-  hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(768), 0, s, (const float*)vimg, uimg, scale, shift,
-                     res, y, d_count, N, T, relu);
+  const int blocks = (int)wino_blocks(bcap, T);
+  const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm4
+  const dim3 grid(8 * per_xcd), block(256);
+#ifdef AGZ_TIMING_EXPERIMENTS
+  static const int xp = getenv("AGZ_WINO_X") ? atoi(getenv("AGZ_WINO_X")) : 0;
+  if (xp && y && vnext && res) {
+    auto kern = xp == 1 ? k_wino_gemm4<3, 1> : xp == 2 ? k_wino_gemm4<3, 2> : xp == 3 ? k_wino_gemm4<3, 3>
+              : xp == 4 ? k_wino_gemm4<3, 4> : xp == 5 ? k_wino_gemm4<3, 5> : xp == 6 ? k_wino_gemm4<3, 6>
+              : xp == 11 ? k_wino_gemm4<1, 0> : xp == 12 ? k_wino_gemm4<2, 0> : k_wino_gemm4<3, 0>;
+    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, xp == 12 ? nullptr : res, y, vnext, d_count, N, T, relu);
+    return;
+  }
+#endif
+  if (y && vnext)
+    hipLaunchKernelGGL((k_wino_gemm4<3>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+  else if (vnext)
+    hipLaunchKernelGGL((k_wino_gemm4<2>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+  else
+    hipLaunchKernelGGL((k_wino_gemm4<1>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
 }
 
 }  // namespace agz

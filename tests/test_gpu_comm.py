@@ -42,15 +42,18 @@ def test_allgather_records_through_the_c_abi_over_rccl():
     assert e0.replay_count() == 0
     assert e0.allgather_records(comm) == 6                       # RCCL all-gather, world of one rank
     assert e0.replay_count() == 6 and e0.replay_positions() == sum(r["num_moves"] for r in want0)
-    for k, w in enumerate(want0):
-        assert same_record(e0.replay_record(k), w), k
+    by_id = {int(r["game_id"]): r for r in want0 + want1}        # (records() sorts by game id, the arena keeps arrival order)
+    for k in range(6):
+        got = e0.replay_record(k)
+        assert same_record(got, by_id[int(got["game_id"])]), k
     # "rank 1": its packed export enters the same arena, once from host memory and once more from device memory
     assert e0.replay_ingest(e1.records_packed()) == 5
     dev = e1.records_packed_device()
     assert e0.replay_ingest((dev.data_ptr(), dev.numel())) == 5
     assert e0.replay_count() == 16
-    for k, w in enumerate(want1):
-        assert same_record(e0.replay_record(6 + k), w) and same_record(e0.replay_record(11 + k), w), k
+    for k in range(5):
+        a, b = e0.replay_record(6 + k), e0.replay_record(11 + k)
+        assert int(a["game_id"]) % 2 == 1 and same_record(a, by_id[int(a["game_id"])]) and same_record(b, a), k
     ids = sorted(e0.replay_record(k)["game_id"] for k in range(11))
     assert ids == list(range(11))                                # game ids r, r + W, ...: the shards interleave
     # a second generation appends; the engine's own ring is the caller's to clear
