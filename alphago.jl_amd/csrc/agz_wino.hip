@@ -215,8 +215,12 @@ __device__ __forceinline__ void glds16s(const float* gbase_uniform, unsigned lan
 // K loop: operands are read 4 planes (>= 256 MFMA cycles) ahead through a ring of 5 register pairs; the stage
 // barrier sits in the READ stream (before the first read of the next stage, i.e. 4 planes before the stage's
 // last MFMA), so the MFMAs of planes 21..24 cover the barrier and the first LDS latencies of the next stage.
-constexpr int IMG_STRIDE = 68;    // floats per board point of the LDS board image: 16-B aligned rows, and
-                                  // 4*pt + c (mod 64) spreads the tiles of a wave over the banks
+// The epilogue's tile image: img[X][16 units of 16 B], X = tile row * 9 + output k, this workgroup's 64 channels
+// of output point X.  Unit u holds channel group u ^ (X & 15): rows are exactly 256 B (an LDS-DMA instruction
+// fills four of them, each lane choosing the global 16 B that belongs in its slot), a wave whose lanes are
+// tile rows reads one channel group of 16 different X per LDS cycle from 16 different units, and a wave whose
+// lanes are channels touches every bank once.
+constexpr int IMG_FLOATS = WT * 9 * WC;          // 147,456 B
 
 // MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
 // X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
   __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+  __shared__ int ptab[WT * 9];     // element offset of output point X in y / res, or -1 (off the board / dead row)
   const int P = N * N, TT = T * T;
   const int RPB = wino_rows_per_block(T);
   const long Mt = (long)(*d_count) * TT;
@@ -254,6 +259,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const float* g = wave < 2 ? asrc + (long)st * A_STAGE + c * 256 : bsrc + (long)st * B_STAGE + (c - 26) * 256;
     glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
   };
+
+  for (int idx = tid; idx < WT * 9; idx += 256) {     // (published by the barrier in front of the first operand reads)
+    const int row = idx / 9, k = idx % 9;
+    const long tile = (long)tb * RPB + row;
+    int off = -1;
+    if (row < RPB && tile < Mt) {
+      const int b = (int)(tile / TT), t = (int)(tile % TT);
+      const int pi = 3 * (t / T) + k / 3, pj = 3 * (t % T) + k % 3;
+      if (pi < N && pj < N) off = (b * P + pi + N * pj) * kC + cb * WC;      // < 2^31: 8192 x 361 x 256 = 7.6e8
+    }
+    ptab[idx] = off;
+  }
 
   f32x16 acc[WXI];
 #pragma unroll
@@ -315,17 +332,17 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     for (int k = 0; k < WXI; ++k) {
       const int t = k + LA;
       if (t == WXI && next) {
-        // everything this wave owes to stage st+1 has landed (its share of stage st+2 issued so far, 11 of 13,
-        // may still be in flight); hipcc adds lgkmcnt(0) in front of the barrier: all reads of stage st are back
-        if (more && X != 4) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        // everything this wave owes to stage st+1 has landed (its share of stage st+2, all 13 pieces issued by
+        // now, may still be in flight); hipcc adds lgkmcnt(0) in front of the barrier: all reads of stage st are back
+        if (more && X != 4) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
       if (t < WXI) load(L, t, ra[t % RING], rb[t % RING]);
       else if (next) load(Ln, t - WXI, ra[t % RING], rb[t % RING]);
-      if (more && (k & 1) == 0) {
+      if (more && k >= 6 && k < 19) {     // one piece per plane slot in the middle of the stage (vs every other slot: -2 %)
         __builtin_amdgcn_sched_barrier(0);
-        if (X != 4) dma(st + 2, dbuf, k >> 1);
+        if (X != 4) dma(st + 2, dbuf, k - 6);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (X != 5) mma(k, ra[k % RING], rb[k % RING]);
@@ -350,30 +367,26 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     return;
   }
 
-  // ---- epilogue.  The stage buffers are dead once every wave has left the K loop; they become
-  //   img   [64 tile rows][9 outputs][IMG_STRIDE]  this workgroup's 64 x 64 x 9 activations (channel fastest)
-  //   ptab  [64 x 9] element offset of output (row, k) in y / res, or -1 (outside the board / dead row)
-  // Three phases, each a flat loop with every memory operation of the phase in flight at once -- a lone wave
+  // ---- epilogue.  The stage buffers are dead once every wave has left the K loop; they become the tile image
+  // img (layout above).  Phases, each with every memory operation of the phase in flight at once -- a lone wave
   // per SIMD has nobody to hide a load -> use round trip behind:
-  //   1   inverse transform A^T M A + BatchNorm affine in registers -> img            (no global memory)
-  //   1b  img (+ residual) -> ReLU -> y and back to img: 256-byte runs per output point, 16 B per lane;
-  //       skipped when there is neither a residual nor a y to write (conv1 of a block: ReLU happens in 1)
+  //   0   residual -> img by LDS-DMA (144 KB in 144 instructions), in flight during the register work of phase 1
+  //   1   inverse transform A^T M A + BatchNorm affine in registers, then img += value (ds_add_f32) or img = value
+  //   1b  img -> ReLU -> y and back to img: 256-byte runs per output point, 16 B per lane; skipped when there is
+  //       neither a residual nor a y to write (conv1 of a block: ReLU happens in phase 1)
   //   2   next layer's input transform V = B^T d B from img -> HBM stage images   (MODE & 2)
   __syncthreads();
   float* img = lds;
-  int* ptab = reinterpret_cast<int*>(lds + WT * 9 * IMG_STRIDE);
-  static_assert(WT * 9 * IMG_STRIDE + WT * 9 <= 3 * STAGE, "tile image + point table exceed the stage buffers");
+  static_assert(IMG_FLOATS <= 3 * STAGE, "tile image exceeds the stage buffers");
   const bool pass1b = (MODE & 1) || res != nullptr;
-  for (int idx = tid; idx < WT * 9; idx += 256) {
-    const int row = idx / 9, k = idx % 9;
-    const long tile = (long)tb * RPB + row;
-    int off = -1;
-    if (row < RPB && tile < Mt) {
-      const int b = (int)(tile / TT), t = (int)(tile % TT);
-      const int pi = 3 * (t / T) + k / 3, pj = 3 * (t % T) + k % 3;
-      if (pi < N && pj < N) off = (b * P + pi + N * pj) * kC + cb * WC;      // < 2^31: 8192 x 361 x 256 = 7.6e8
+  if (res) {
+    // instruction i fills points 4i .. 4i+3: lane = (point, unit u) fetches channel group u ^ (X & 15)
+    for (int i = wave; i < WT * 9 / 4; i += 4) {
+      const int Xp = 4 * i + (lane >> 4), u = lane & 15;
+      const int off = ptab[Xp];
+      const float* g = res + (off >= 0 ? off + 4 * (u ^ (Xp & 15)) : 0);      // dead points: any valid address
+      glds16(g, lds0 + (unsigned)(i * 256) * 4u);
     }
-    ptab[idx] = off;
   }
   {
     // phase 1.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -400,15 +413,20 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
         o[i * 3 + 2] = ((tmp[i][1] + tmp[i][2]) + 4.f * tmp[i][3]) + tmp[i][4];
       }
     }
+    if (res) {                                    // the residual tile has landed, for every wave
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-      float* dst = img + row * 9 * IMG_STRIDE + col;
+      const int Xr = (wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi) * 9;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         float v = o[k][e] * sc + sh;
         if (relu_now) v = fmaxf(v, 0.f);
-        dst[k * IMG_STRIDE] = v;
+        float* dst = img + (Xr + k) * WC + 4 * ((col >> 2) ^ ((Xr + k) & 15)) + (col & 3);
+        if (res) __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // ds_add_f32
+        else *dst = v;
       }
     }
   }
@@ -417,26 +435,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   if (pass1b) {
     // phase 1b: element = (row, k, 4 channels); 16 consecutive lanes cover the 256 contiguous bytes of one point
     constexpr int PER = WT * 9 * (WC / 4) / 256;      // 36 per thread
-    f32x4 rv[PER];
-    int offs[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int idx = tid + 256 * i;
-      offs[i] = ptab[idx >> 4];
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      rv[i] = (res && offs[i] >= 0) ? *reinterpret_cast<const f32x4*>(res + offs[i] + 4 * (idx & 15)) : z;
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int idx = tid + 256 * i;
-      if (offs[i] < 0) continue;
-      f32x4* ip = reinterpret_cast<f32x4*>(img + (idx >> 4) * IMG_STRIDE + 4 * (idx & 15));
-      f32x4 v = *ip + rv[i];
+      const int idx = tid + 256 * i, Xp = idx >> 4;
+      const int off = ptab[Xp];
+      if (off < 0) continue;
+      f32x4* ip = reinterpret_cast<f32x4*>(img + idx * 4);       // unit idx & 15 of point Xp holds group (idx ^ Xp) & 15
+      f32x4 v = *ip;
       if (relu) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
       }
-      if (MODE & 1) *reinterpret_cast<f32x4*>(y + offs[i] + 4 * (idx & 15)) = v;
+      if (MODE & 1) *reinterpret_cast<f32x4*>(y + off + 4 * ((idx ^ Xp) & 15)) = v;
       if (MODE & 2) *ip = v;
     }
     if (MODE & 2) __syncthreads();
@@ -460,17 +470,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
         const int pi = 3 * ti - 1 + u, pj = 3 * tj - 1 + v;
         const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
         // the point lives in tile (pi / 3, pj / 3) of the same board, output k = (pi % 3) * 3 + pj % 3
-        poff[u * 5 + v] = ok ? ((lb * TT + (pi / 3) * T + pj / 3) * 9 + (pi % 3) * 3 + pj % 3) * IMG_STRIDE : -1;
+        poff[u * 5 + v] = ok ? (lb * TT + (pi / 3) * T + pj / 3) * 9 + (pi % 3) * 3 + pj % 3 : -1;      // = X
       }
     // a V image row is one plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1 (wino_v_off)
     const bool swap = (row >> 4) & 1;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 1
     for (int sl = wave; sl < WC / WK; sl += 4) {
       f32x4 d[25];
 #pragma unroll
       for (int q = 0; q < 25; ++q) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + poff[q] + sl * WK) : z;
+        d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + poff[q] * WC + 4 * (sl ^ (poff[q] & 15))) : z;
       }
       float* g = vnext + ((long)tb * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
       // B^T d B on channel PAIRS (v_pk_*_f32: two channels per VALU instruction; no MFMA runs beside this)
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
           if (v4[0] + v4[3] == 123.456f) *gp = v4;
           continue;
         }
-        __builtin_nontemporal_store(v4, gp);
+        __builtin_nontemporal_store(v4, gp);      // 1.9 GB per layer, read back a whole layer later: keep it out of L2
       }
     }
   }

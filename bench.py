@@ -205,6 +205,11 @@ def main():
     # xGMI, device to device).  torch.distributed only carries the 128-byte RCCL unique id to the other ranks.
     exchange = None
     if dist is not None and not args.single_device_test:
+        # RCCL prints a version banner on stdout when a communicator is created; stdout must carry exactly one
+        # JSON line, so the exchange leg runs with fd 1 pointed at stderr
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         try:
             ids = [ag.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
@@ -220,6 +225,10 @@ def main():
             eng.comm_destroy(comm)
         except Exception as ex:      # the exchange leg must never take the self-play number down with it
             exchange = {"error": str(ex)}
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     elapsed = t1 - t0
     d = {k: s1[k] - s0[k] for k in ("positions", "evals", "duplicate_evals", "terminal_visits", "root_visits",
