@@ -293,14 +293,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 
   // 400 accumulators: hipcc gives EVERY MFMA of a kernel the same accumulator register class, so beyond 256 it
   // shuttles tuples between the two halves of the file around every MFMA (308 v_accvgpr moves and 24 scratch
-  // accesses per stage when left alone).  The first NAG planes therefore use the builtin (accumulators in
-  // AGPRs: 16 x 16 = the whole accumulator half) and the other 9 an asm MFMA whose "+v" constraint keeps
-  // their 144 registers in the VGPR half.  Wait states (cdna_hip_programming.md 5.7): an accumulate chain
-  // needs none; the leading s_nop 1 covers a compiler v_mov into an A/B operand; the D -> VALU distance is
-  // padded once, after the K loop.
-  constexpr int NAG = 16;
+  // accesses per stage when left alone).  The planes of transform columns 0..2 (xi % 5 < 3: 15 planes) therefore
+  // use the builtin (accumulators in AGPRs) and the 10 planes of columns 3, 4 an asm MFMA whose "+v" constraint
+  // keeps their 160 registers in the VGPR half -- whole columns, so that the inverse transform can start with the
+  // two columns that are already in VGPRs and free 160 registers before the AGPR columns are read (no spill).
+  // Wait states (cdna_hip_programming.md 5.7): an accumulate chain needs none; the leading s_nop 1 covers a
+  // compiler v_mov into an A/B operand; the D -> VALU distance is padded once, after the K loop.
+  auto in_agpr = [](int k) { return k % 5 < 3; };
   auto mma = [&](int k, const float2& a, const float2& b) {
-    if (k < NAG) {
+    if (in_agpr(k)) {
       acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[k], 0, 0, 0);
       acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
     } else {
@@ -355,10 +356,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 
   // the asm MFMAs' D registers -> VALU readers below: 18 wait states.  The pad must NAME those registers, or the
   // scheduler is free to lift a register-only VALU read of them above it (seen: 4e-4 errors on some lanes)
-  static_assert(NAG == 16 && WXI == 25, "the pad below lists accumulators 16..24");
+  static_assert(WXI == 25, "the pad below lists the accumulators of transform columns 3 and 4");
   asm volatile("s_nop 15\n\ts_nop 15"
-               : "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]),
-                 "+v"(acc[23]), "+v"(acc[24]));
+               : "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[18]),
+                 "+v"(acc[19]), "+v"(acc[23]), "+v"(acc[24]));
   if (X == 1) {
     float keep = 0.f;
 #pragma unroll
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   // img (layout above).  Phases, each with every memory operation of the phase in flight at once -- a lone wave
   // per SIMD has nobody to hide a load -> use round trip behind:
   //   0   residual -> img by LDS-DMA (144 KB in 144 instructions), in flight during the register work of phase 1
-  //   1   inverse transform A^T M A + BatchNorm affine in registers, then img += value (ds_add_f32) or img = value
+  //   1   inverse transform A^T M A + BatchNorm affine in registers, then img = img (the residual) + value
   //   1b  img -> ReLU -> y and back to img: 256-byte runs per output point, 16 B per lane; skipped when there is
   //       neither a residual nor a y to write (conv1 of a block: ReLU happens in phase 1)
   //   2   next layer's input transform V = B^T d B from img -> HBM stage images   (MODE & 2)
@@ -399,7 +400,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     {
       f32x16 tmp[3][5];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
+      for (int jj = 0; jj < 5; ++jj) {
+        const int j = (jj + 3) % 5;          // columns 3, 4 (VGPR-resident) first
         const f32x16 m0 = acc[0 * 5 + j], m1 = acc[1 * 5 + j], m2 = acc[2 * 5 + j], m3 = acc[3 * 5 + j], m4 = acc[4 * 5 + j];
         tmp[0][j] = ((m0 + m1) + m2) + m3;
         tmp[1][j] = (m1 - m2) + 2.f * m3;
@@ -417,18 +419,26 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    // img = (residual +) value.  ds_add_f32 would do the sum in one instruction, but LDS float atomics run at a
+    // fraction of the ds_write rate (+0.75 ms per layer measured): read the nine residuals of a row, add, write
+    auto rows = [&](auto with_res) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int Xr = (wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi) * 9;
+      for (int e = 0; e < 16; ++e) {
+        const int Xr = (wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi) * 9;
+        float rr[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        float v = o[k][e] * sc + sh;
-        if (relu_now) v = fmaxf(v, 0.f);
-        float* dst = img + (Xr + k) * WC + 4 * ((col >> 2) ^ ((Xr + k) & 15)) + (col & 3);
-        if (res) __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // ds_add_f32
-        else *dst = v;
+        for (int k = 0; k < 9; ++k)
+          rr[k] = decltype(with_res)::value ? img[(Xr + k) * WC + 4 * ((col >> 2) ^ ((Xr + k) & 15)) + (col & 3)] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          float v = o[k][e] * sc + sh + rr[k];
+          if (relu_now) v = fmaxf(v, 0.f);
+          img[(Xr + k) * WC + 4 * ((col >> 2) ^ ((Xr + k) & 15)) + (col & 3)] = v;
+        }
       }
-    }
+    };
+    if (res) rows(std::true_type{});
+    else rows(std::false_type{});
   }
   __syncthreads();
   typedef float f32x4 __attribute__((ext_vector_type(4)));
