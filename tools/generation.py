@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=50, help="steps between polls of the finished-game counter")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"])
     ap.add_argument("--max-seconds", type=float, default=1500.0)
+    ap.add_argument("--no-warmup-generation", dest="warmup_generation", action="store_false")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
@@ -47,6 +48,15 @@ def main():
     eng.start(0)
     prelude = (R + 7) // 8 + 5 if args.stagger > 0 else 0
     eng.step(prelude + args.warmup)
+    eng.sync()
+    # warm-up generation ("timing over >= 1 full generation after a warm-up generation"): the first G
+    # games to finish are the staggered start-up population (random opening prefixes that were never searched, all
+    # born at the same moment); the measured window opens when the G-th of them has finished
+    tw = time.perf_counter()
+    if args.warmup_generation:
+        while eng.stats()["games_finished"] < G and time.perf_counter() - tw < args.max_seconds:
+            eng.step(args.chunk)
+    warm_s = time.perf_counter() - tw
     eng.sync()
     eng.records_clear()
     s0 = eng.stats()
@@ -81,7 +91,8 @@ def main():
                         "max": int(nm.max()) if len(nm) else None},
         "results": {"black": int((res > 0).sum()), "white": int((res < 0).sum()), "draw": int((res == 0).sum())},
         "pool_exhausted": s1["pool_exhausted"], "timed_out": wall > args.max_seconds,
-        "setup": {"prelude_steps": prelude, "warmup_steps": args.warmup, "stagger_moves": args.stagger},
+        "setup": {"prelude_steps": prelude, "warmup_steps": args.warmup, "stagger_moves": args.stagger,
+                  "warmup_generation": bool(args.warmup_generation), "warmup_generation_s": warm_s},
     }
     txt = json.dumps(out)
     print(txt, flush=True)
