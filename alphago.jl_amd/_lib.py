@@ -151,6 +151,8 @@ def load():
         "agz_replay_trim": (i32, [E, i64]),
         "agz_replay_clear": (i32, [E]),
         "agz_replay_batch": (i32, [E, P(i64), i32p, i32, C.c_void_p, C.c_void_p, C.c_void_p, i32]),
+        "agz_train_step": (i32, [E, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32, f32, f32, f32p]),
+        "agz_train_reset": (i32, [E]),
         "agz_comm_unique_id": (i32, [P(C.c_uint8)]),
         "agz_comm_create": (i32, [E, i32, i32, P(C.c_uint8), P(E)]),
         "agz_comm_destroy": (None, [E]),

@@ -247,6 +247,12 @@ agz_status agz_replay_batch(agz_engine* e, const int64_t* game, const int32_t* p
   return guard(e, [&](agz::Engine& E) { E.replay_batch(game, ply, B, feats, pi, z, out_is_device != 0); });
 }
 
+agz_status agz_train_step(agz_engine* e, const float* feats, const float* pi, const float* z, int32_t B,
+                          int32_t inputs_are_device, float eta, float rho, float* losses_out) {
+  return guard(e, [&](agz::Engine& E) { E.train_step(feats, pi, z, B, inputs_are_device != 0, eta, rho, losses_out); });
+}
+agz_status agz_train_reset(agz_engine* e) { return guard(e, [&](agz::Engine& E) { E.train_reset(); }); }
+
 // ---- RCCL exchange (agz_comm.hip)
 agz_status agz_comm_unique_id(uint8_t* id_out) {
   if (!id_out) return AGZ_BAD_ARGUMENT;

@@ -59,6 +59,10 @@ class Engine {
   void replay_batch(const int64_t* game, const int32_t* ply, int B, float* feats, float* pi, float* z,
                     bool out_is_device);
   DevBuf<uint8_t>& pack_scratch() { return s_pack_; }
+  // one optimisation step on the selected network (agz_train.hip)
+  void train_step(const float* feats, const float* pi, const float* z, int B, bool is_device, float eta, float rho,
+                  float* losses_out);
+  void train_reset();
   // flat parameter vector of the selected network in layers() order (broadcast_weights)
   std::vector<float> weights_flat();
   void weights_set_flat(const std::vector<float>& w);
@@ -112,6 +116,7 @@ class Engine {
   View V_{};
   hipStream_t stream_ = nullptr;
   std::unique_ptr<Net> net_, net2_;   // net2_: White's network in arena mode
+  std::unique_ptr<Trainer> trainer_, trainer2_;
   int net_sel_ = 0;
   int external_batch2_ = 0;
   std::vector<void*> bufs_;

@@ -767,6 +767,18 @@ void Engine::replay_clear() {
   rp_positions_ = 0;
 }
 
+void Engine::train_step(const float* feats, const float* pi, const float* z, int B, bool is_device, float eta, float rho,
+                        float* losses_out) {
+  std::unique_ptr<Trainer>& tr = (net_sel_ && net2_) ? trainer2_ : trainer_;
+  if (!tr) tr.reset(new Trainer(net(), stream_));
+  tr->step(feats, pi, z, B, is_device, eta, rho, losses_out);
+}
+
+void Engine::train_reset() {
+  std::unique_ptr<Trainer>& tr = (net_sel_ && net2_) ? trainer2_ : trainer_;
+  if (tr) tr->reset();
+}
+
 // every parameter of the selected network as one flat vector, in a fixed (layer, kind) order
 static void weight_keys(int tower, std::vector<std::pair<int, int>>& keys) {
   for (int l = 0; l <= 2 * tower; ++l)

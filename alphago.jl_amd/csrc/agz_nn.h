@@ -3,6 +3,7 @@
 // /root/reference/src/resnet.jl:11-32.  See DESIGN.md "Network kernels".
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "agz_common.h"
@@ -56,15 +57,18 @@ class Net {
   void profile_enable(bool on);
   void profile_read(double* total_ms, double* total_flop, int64_t* launches);
 
+  // training (agz_train.hip): host parameters by layer id, and "the device packs are stale"
+  ConvHost* conv(int layer);
+  const ConvHost* conv(int layer) const;
+  DenseHost* dense(int layer);
+  const DenseHost* dense(int layer) const;
+  void mark_dirty() { dirty_ = true; packed16_ = false; }
+
   double flops_per_eval() const;         // BASELINE.md F_eval
   double conv_flops_per_launch(int B) const { return 2.0 * B * P_ * 9.0 * kC * kC; }
 
  private:
   void pack();
-  ConvHost* conv(int layer);
-  const ConvHost* conv(int layer) const;
-  DenseHost* dense(int layer);
-  const DenseHost* dense(int layer) const;
 
   int N_, P_, A_, tower_;
   hipStream_t stream_;
@@ -95,6 +99,34 @@ class Net {
   int prof_n_ = 0, prof_fwd_ = 0;
   static constexpr int kProfMax = 4096;
 };
+
+// One optimisation step of `_train` on the device (agz_train.hip; /root/reference/src/neural_net.jl:75-101)
+class Trainer {
+ public:
+  Trainer(Net& net, hipStream_t s);
+  ~Trainer();
+  // feats [B][17 P] (agz_features order), pi [B][A], z [B]: all host or all device pointers; losses_out[4] =
+  // {total, policy, value, regulariser} before the update
+  void step(const float* feats, const float* pi, const float* z, int B, bool is_device, float eta, float rho,
+            float* losses_out);
+  void reset();     // forget the optimiser state (Momentum velocities)
+
+ private:
+  struct Param;
+  void upload();
+  void download(const std::vector<std::vector<float>>& bn_mean, const std::vector<std::vector<float>>& bn_var, long M);
+  Net& net_;
+  hipStream_t stream_;
+  std::vector<std::unique_ptr<Param>> params_;
+  bool have_vel_ = false;
+  DevBuf<float> d_x32_, d_u_, d_o_, d_ga_, d_gb_, d_gc_, d_stats_, d_ones_, d_zero_, d_wd_, d_small_, d_in_;
+  DevBuf<double> d_sums_;
+  DevBuf<int> d_cnt_;
+};
+
+// the direct implicit-GEMM 3x3 convolution of agz_nn.hip (y = act(scale * conv + shift (+ res))), cin_pad = 32 or 256
+void launch_conv3x3_direct(const float* x, const float* wt, const float* scale, const float* shift, const float* res,
+                           float* y, const int* d_count, int bcap, int N, int relu, int cin_pad, hipStream_t s);
 
 // Winograd F(3x3,3x3) tower convolution (agz_wino.hip)
 void wino_pack_weights(const ConvHost& c, float* out);

@@ -559,6 +559,15 @@ void Net::reserve(int bcap) {
 
 static inline int conv_grid(int bcap, int P) { return ceil_div((long)bcap * P, BM) * (kC / BN); }
 
+void launch_conv3x3_direct(const float* x, const float* wt, const float* scale, const float* shift, const float* res,
+                           float* y, const int* d_count, int bcap, int N, int relu, int cin_pad, hipStream_t s) {
+  const int grid = conv_grid(bcap, N * N);
+  if (cin_pad == kCinStemPad)
+    hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad>), dim3(grid), dim3(256), 0, s, x, wt, scale, shift, res, y, d_count, N, relu);
+  else
+    hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, s, x, wt, scale, shift, res, y, d_count, N, relu);
+}
+
 void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi, float* d_v) {
   pack();
   reserve(bcap);

@@ -1,0 +1,658 @@
+// agz_train.hip -- one optimisation step of the policy/value network on the device.
+//
+// Reference: `_train` and its three losses, /root/reference/src/neural_net.jl:75-101; the optimiser
+// `Momentum(2f-2)`, /root/reference/src/train.jl:54; the call, train.jl:67-74.  `_train` is broken at the
+// reference's HEAD (undefined `loss_avg`, un-imported `update!`, `params(nn)` of a struct that is not a functor,
+// a B-vector minus a 1 x B matrix in `loss_value`), so what is restated here is the INTENDED step:
+//
+//   p, v  = nn(positions, train = true)            BatchNorm normalises with the batch's own statistics and
+//                                                  moves its running statistics by momentum 0.1 (Flux BatchNorm)
+//   loss  = 0.01 * (-sum(pi .* log(p)) / B)        loss_pi     = crossentropy(p, pi; weight = 0.01)
+//         + 0.01 * mean((v - z)^2)                 loss_value  = 0.01 * mse(z, v)
+//         + 1e-4 * sum over every parameter of theta^2          loss_reg
+//   back!(loss); update!(Momentum(eta = 0.02, rho = 0.9), params):   vel = rho vel - eta grad;  theta += vel
+//
+// It is pinned by a torch float64 autograd twin of the same network (tests/test_gpu_train.py), not by the
+// reference ("parity unpinned": the reference cannot run this step).
+//
+// Layout: activations [M = B P][C] f32, channel fastest, exactly as the inference path; the 3x3 convolutions
+// (forward and input gradient) run on the same f32-MFMA implicit GEMM as inference (k_conv3x3_mfma with an
+// identity affine); everything else -- batch statistics, BatchNorm forward/backward, weight gradients, the heads,
+// the optimiser -- is plain HIP: at the reference's batch of 32 positions a step is a few GFLOP, and this row is
+// about having the step on the device with the right numbers, not about its roofline.
+#include <cmath>
+#include <cstring>
+
+#include "agz_nn.h"
+
+namespace agz {
+
+namespace {
+
+constexpr float kLossPiW = 0.01f, kLossVW = 0.01f, kRegW = 1e-4f, kBnMomentum = 0.1f;
+
+// ---- column statistics: sums[c] = sum_m u[m][c], sums[C + c] = sum_m u[m][c]^2 (double, atomics over row slices)
+__global__ __launch_bounds__(256) void k_colsums(const float* __restrict__ u, long M, int C, double* __restrict__ sums) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s = 0.0, s2 = 0.0;
+  if (c < C)
+    for (long m = (long)blockIdx.y * 4 + rl; m < M; m += (long)gridDim.y * 4) {
+      const double v = u[m * C + c];
+      s += v;
+      s2 += v * v;
+    }
+  red[0][rl][cl] = s;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    atomicAdd(&sums[c], red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    atomicAdd(&sums[C + c], red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+  }
+}
+
+// BatchNorm forward with batch statistics: out = act(gamma (u - mean) rstd + beta (+ res)); stats = {mean, var, rstd}[C]
+__global__ void k_bn_fwd(const float* __restrict__ u, long M, int C, const double* __restrict__ sums,
+                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                         const float* __restrict__ res, float* __restrict__ out, int relu, float* __restrict__ stats) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  const int c = (int)(i % C);
+  const double mean = sums[c] / (double)M;
+  const double var = fmax(sums[C + c] / (double)M - mean * mean, 0.0);
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (i < C) { stats[c] = (float)mean; stats[C + c] = (float)var; stats[2 * C + c] = (float)rstd; }
+  float v = (float)(((double)u[i] - mean) * rstd) * gamma[c] + beta[c];
+  if (res) v += res[i];
+  if (relu) v = fmaxf(v, 0.f);
+  out[i] = v;
+}
+
+// BatchNorm backward, reduction: with dy = dout (.* [out > 0] if relu): sums[c] = sum dy, sums[C + c] = sum dy xhat
+__global__ __launch_bounds__(256) void k_bn_bwd_sums(const float* __restrict__ dout, const float* __restrict__ out,
+                                                      const float* __restrict__ u, const float* __restrict__ stats,
+                                                      long M, int C, int relu, double* __restrict__ sums) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s = 0.0, s2 = 0.0;
+  if (c < C) {
+    const double mean = stats[c], rstd = stats[2 * C + c];
+    for (long m = (long)blockIdx.y * 4 + rl; m < M; m += (long)gridDim.y * 4) {
+      const long i = m * C + c;
+      const double dy = (relu && !(out[i] > 0.f)) ? 0.0 : (double)dout[i];
+      s += dy;
+      s2 += dy * ((double)u[i] - mean) * rstd;
+    }
+  }
+  red[0][rl][cl] = s;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    atomicAdd(&sums[c], red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    atomicAdd(&sums[C + c], red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+  }
+}
+
+// du = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)); dres (optional) = dy: the shortcut's share of a block output
+__global__ void k_bn_bwd_apply(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ u,
+                               const float* __restrict__ stats, const float* __restrict__ gamma,
+                               const double* __restrict__ sums, long M, int C, int relu, float* __restrict__ du,
+                               float* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  const int c = (int)(i % C);
+  const double mean = stats[c], rstd = stats[2 * C + c];
+  const double dy = (relu && !(out[i] > 0.f)) ? 0.0 : (double)dout[i];
+  const double xhat = ((double)u[i] - mean) * rstd;
+  du[i] = (float)((double)gamma[c] * rstd * (dy - sums[c] / (double)M - xhat * sums[C + c] / (double)M));
+  if (dres) dres[i] = (float)dy;
+  if (i < C) { dgamma[c] = (float)sums[C + c]; dbeta[c] = (float)sums[c]; }
+}
+
+// out[c] = (float) sums[c]  (bias gradients = column sums of du)
+__global__ void k_take_sums(const double* __restrict__ sums, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = (float)sums[c];
+}
+
+// 3x3 weight gradient in the packed layout of the forward kernel: dWt[co][tap][ci] = sum_m du[m][co] x[m + shift(tap)][ci]
+// grid (256/32, 9, CIN/32), 256 threads: a 32 x 32 (co x ci) tile per block, 4 outputs per thread, rows in chunks of 32
+__global__ __launch_bounds__(256) void k_wgrad3x3(const float* __restrict__ x, const float* __restrict__ du, int B, int N,
+                                                   int CIN, float* __restrict__ dwt) {
+  __shared__ float sd[32][33], sx[32][33];
+  const int P = N * N;
+  const long M = (long)B * P;
+  const int co0 = blockIdx.x * 32, tap = blockIdx.y, ci0 = blockIdx.z * 32;
+  const int da = tap % 3 - 1, db = tap / 3 - 1;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty 0..7
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (long m0 = 0; m0 < M; m0 += 32) {
+    for (int r = ty; r < 32; r += 8) {
+      const long m = m0 + r;
+      float dv = 0.f, xv = 0.f;
+      if (m < M) {
+        dv = du[m * kC + co0 + tx];
+        const int p = (int)(m % P), ri = p % N, cj = p / N;
+        if ((unsigned)(ri + da) < (unsigned)N && (unsigned)(cj + db) < (unsigned)N) xv = x[(m + da + N * db) * CIN + ci0 + tx];
+      }
+      sd[r][tx] = dv;
+      sx[r][tx] = xv;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      const float xv = sx[r][tx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += (double)sd[r][ty + 8 * q] * (double)xv;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dwt[((long)(co0 + ty + 8 * q) * 9 + tap) * CIN + ci0 + tx] = (float)acc[q];
+}
+
+// ---- heads, forward (raw, before BatchNorm): cv[m] = x[m] . wv + bv;  cp[m][j] = x[m] . wp[j] + bp[j]
+__global__ __launch_bounds__(256) void k_head1x1_fwd(const float* __restrict__ x, long M, const float* __restrict__ wv,
+                                                      const float* __restrict__ bv, const float* __restrict__ wp,
+                                                      const float* __restrict__ bp, float* __restrict__ cv,
+                                                      float* __restrict__ cp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+    double dv = 0.0, d0 = 0.0, d1 = 0.0;
+    for (int c = lane; c < kC; c += 64) {
+      const double xv = x[m * kC + c];
+      dv += xv * wv[c];
+      d0 += xv * wp[c];
+      d1 += xv * wp[kC + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      dv += __shfl_xor(dv, o, 64);
+      d0 += __shfl_xor(d0, o, 64);
+      d1 += __shfl_xor(d1, o, 64);
+    }
+    if (lane == 0) {
+      cv[m] = (float)(dv + bv[0]);
+      cp[m * 2 + 0] = (float)(d0 + bp[0]);
+      cp[m * 2 + 1] = (float)(d1 + bp[1]);
+    }
+  }
+}
+
+// Dense forward: out[b][o] = act(sum_i W[o + O i] in[b][i] + bias[o]); act 0 none, 1 relu, 2 tanh.  in index map:
+// in_mode 0: in[b*I + i]; 1: value head hv[(b*P + i)]; 2: policy head hp[((b*P + p)*2 + c)] with i = p + P c
+__device__ __forceinline__ long in_index(int mode, int b, int i, int I, int P) {
+  if (mode == 2) return ((long)b * P + (i % P)) * 2 + (i / P);
+  return (long)b * I + i;
+}
+__global__ void k_dense_fwd(const float* __restrict__ in, int in_mode, int P, const float* __restrict__ W,
+                            const float* __restrict__ bias, int B, int I, int O, int act, float* __restrict__ out) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (o >= O) return;
+  double s = bias[o];
+  for (int i = 0; i < I; ++i) s += (double)W[o + (long)O * i] * (double)in[in_index(in_mode, b, i, I, P)];
+  float v = (float)s;
+  if (act == 1) v = fmaxf(v, 0.f);
+  if (act == 2) v = tanhf(v);
+  out[(long)b * O + o] = v;
+}
+
+// softmax + the two data losses + the gradients at the network outputs.
+//   dlogit[b][a] = w_pi / B * (p_a * sum(pi) - pi_a);  ds[b] = 2 w_v / B * (v - z) * (1 - v^2)   (through tanh)
+// losses[0] += -w_pi / B * sum pi log p;  losses[1] += w_v / B * (v - z)^2
+__global__ __launch_bounds__(256) void k_outputs(const float* __restrict__ logits, const float* __restrict__ v,
+                                                  const float* __restrict__ pi, const float* __restrict__ z, int B, int A,
+                                                  float* __restrict__ p_out, float* __restrict__ dlogit,
+                                                  float* __restrict__ ds, double* __restrict__ losses) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double mx = -1e300;
+  for (int a = tid; a < A; a += 256) mx = fmax(mx, (double)logits[(long)b * A + a]);
+  red[tid] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
+  mx = red[0];
+  __syncthreads();
+  double se = 0.0, spi = 0.0;
+  for (int a = tid; a < A; a += 256) { se += exp((double)logits[(long)b * A + a] - mx); spi += pi[(long)b * A + a]; }
+  red[tid] = se;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  se = red[0];
+  __syncthreads();
+  red[tid] = spi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  spi = red[0];
+  __syncthreads();
+  double lp = 0.0;
+  for (int a = tid; a < A; a += 256) {
+    const double lg = (double)logits[(long)b * A + a] - mx - log(se);      // log p
+    const double p = exp(lg), t = pi[(long)b * A + a];
+    p_out[(long)b * A + a] = (float)p;
+    dlogit[(long)b * A + a] = (float)((double)kLossPiW / B * (p * spi - t));
+    if (t != 0.0) lp += t * lg;
+  }
+  red[tid] = lp;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) {
+    const double dv = (double)v[b] - (double)z[b];
+    atomicAdd(&losses[0], -(double)kLossPiW / B * red[0]);
+    atomicAdd(&losses[1], (double)kLossVW / B * dv * dv);
+    ds[b] = (float)(2.0 * kLossVW / B * dv * (1.0 - (double)v[b] * (double)v[b]));
+  }
+}
+
+// Dense backward.  dW[o + O i] = sum_b dout[b][o] in[b][i];  db[o] = sum_b dout[b][o]
+__global__ void k_dense_wgrad(const float* __restrict__ in, int in_mode, int P, const float* __restrict__ dout, int B, int I,
+                              int O, float* __restrict__ dW, float* __restrict__ dbias) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)O * I) return;
+  const int o = (int)(idx % O), i = (int)(idx / O);
+  double s = 0.0, sb = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double d = dout[(long)b * O + o];
+    s += d * (double)in[in_index(in_mode, b, i, I, P)];
+    sb += d;
+  }
+  dW[idx] = (float)s;
+  if (i == 0) dbias[o] = (float)sb;
+}
+// din[b][i] = sum_o W[o + O i] dout[b][o]  (* [out_prev > 0] if the producing layer ended in a ReLU)
+__global__ void k_dense_dgrad(const float* __restrict__ W, const float* __restrict__ dout, int B, int I, int O,
+                              const float* __restrict__ act_out, int in_mode, int P, float* __restrict__ din) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (i >= I) return;
+  double s = 0.0;
+  for (int o = 0; o < O; ++o) s += (double)W[o + (long)O * i] * (double)dout[(long)b * O + o];
+  const long j = in_index(in_mode, b, i, I, P);
+  if (act_out && !(act_out[in_mode == 0 ? (long)b * I + i : j] > 0.f)) s = 0.0;
+  din[j] = (float)s;
+}
+
+// heads, backward of the 1x1 convolutions: dx[m][c] = dcv[m] wv[c] + dcp[m][0] wp[c] + dcp[m][1] wp[256 + c]
+__global__ void k_head1x1_dgrad(const float* __restrict__ dcv, const float* __restrict__ dcp, const float* __restrict__ wv,
+                                const float* __restrict__ wp, long M, float* __restrict__ dx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * kC) return;
+  const long m = i / kC;
+  const int c = (int)(i % kC);
+  dx[i] = dcv[m] * wv[c] + dcp[m * 2] * wp[c] + dcp[m * 2 + 1] * wp[kC + c];
+}
+// dwv[c] = sum_m dcv[m] x[m][c]; dwp[j][c]; dbv, dbp: one thread per channel (M <= a few 10^4)
+__global__ void k_head1x1_wgrad(const float* __restrict__ x, const float* __restrict__ dcv, const float* __restrict__ dcp,
+                                long M, float* __restrict__ dwv, float* __restrict__ dwp, float* __restrict__ dbv,
+                                float* __restrict__ dbp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= kC) return;
+  double sv = 0.0, s0 = 0.0, s1 = 0.0, bv = 0.0, b0 = 0.0, b1 = 0.0;
+  for (long m = 0; m < M; ++m) {
+    const double xv = x[m * kC + c];
+    sv += xv * dcv[m];
+    s0 += xv * dcp[m * 2];
+    s1 += xv * dcp[m * 2 + 1];
+    if (c == 0) { bv += dcv[m]; b0 += dcp[m * 2]; b1 += dcp[m * 2 + 1]; }
+  }
+  dwv[c] = (float)sv;
+  dwp[c] = (float)s0;
+  dwp[kC + c] = (float)s1;
+  if (c == 0) { dbv[0] = (float)bv; dbp[0] = (float)b0; dbp[1] = (float)b1; }
+}
+
+__global__ void k_add(float* __restrict__ a, const float* __restrict__ b, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+
+// sum theta^2 (loss_reg) -> losses[2]
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ t, long n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += (double)t[i] * (double)t[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
+// Momentum (Flux): g = grad + 2 * 1e-4 * theta; vel = rho vel - eta g; theta += vel
+__global__ void k_momentum(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ vel, long n, float eta,
+                           float rho) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = grad[i] + 2.f * kRegW * theta[i];
+  const float v = rho * vel[i] - eta * g;
+  vel[i] = v;
+  theta[i] += v;
+}
+
+// input-gradient weights of a 256 -> 256 layer: Wd[ci][tap'][co] = Wt[co][8 - tap'][ci]  (shift(8 - tap) = -shift(tap))
+__global__ void k_make_wd(const float* __restrict__ wt, float* __restrict__ wd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)kC * 9 * kC) return;
+  const int co = (int)(i % kC), tp = (int)((i / kC) % 9), ci = (int)(i / (9 * kC));
+  wd[i] = wt[((long)co * 9 + (8 - tp)) * kC + ci];
+}
+
+inline dim3 g1(long n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+}  // namespace
+
+// ------------------------------------------------------------------ the trainer
+
+struct Trainer::Param {
+  DevBuf<float> theta, grad, vel;
+  size_t n = 0;
+};
+
+Trainer::Trainer(Net& net, hipStream_t s) : net_(net), stream_(s) {}
+Trainer::~Trainer() {}
+
+void Trainer::reset() { have_vel_ = false; }
+
+// host parameters (Flux layouts) -> training layouts on the device.  Convolutions: Wt[cout][tap][cin_pad], the layout
+// of the forward kernel (true-convolution flip applied); everything else as it is.
+void Trainer::upload() {
+  const int t = net_.tower(), L = 1 + 2 * t;
+  if (params_.empty())
+    for (size_t i = 0; i < (size_t)4 * L + 8 + 6; ++i) params_.emplace_back(new Param);
+  auto put = [&](Param& p, const std::vector<float>& h) {
+    p.n = h.size();
+    p.theta.ensure(p.n);
+    p.grad.ensure(p.n);
+    if (p.vel.n < p.n) { p.vel.ensure(p.n); have_vel_ = false; }
+    AGZ_HIP(hipMemcpyAsync(p.theta.p, h.data(), sizeof(float) * p.n, hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
+  };
+  for (int l = 0; l < L; ++l) {
+    const ConvHost& c = *net_.conv(l);
+    const int cinp = l == 0 ? kCinStemPad : kC;
+    std::vector<float> w((size_t)kC * 9 * cinp, 0.f);
+    for (int o = 0; o < kC; ++o)
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          for (int ci = 0; ci < c.cin; ++ci)
+            w[((size_t)o * 9 + (2 - a) + 3 * (2 - b)) * cinp + ci] = c.w[a + 3 * (b + 3 * (ci + (size_t)c.cin * o))];
+    put(*params_[4 * l + 0], w);
+    put(*params_[4 * l + 1], c.b);
+    put(*params_[4 * l + 2], c.gamma);
+    put(*params_[4 * l + 3], c.beta);
+  }
+  size_t k = (size_t)4 * L;
+  for (int l : {AGZ_L_VALUE_CONV, AGZ_L_POLICY_CONV}) {
+    const ConvHost& c = *net_.conv(l);
+    put(*params_[k++], c.w);            // [1,1,256,cout] column-major = w[ci + 256 o]
+    put(*params_[k++], c.b);
+    put(*params_[k++], c.gamma);
+    put(*params_[k++], c.beta);
+  }
+  for (int l : {AGZ_L_VALUE_FC1, AGZ_L_VALUE_FC2, AGZ_L_POLICY_FC}) {
+    const DenseHost& d = *net_.dense(l);
+    put(*params_[k++], d.w);
+    put(*params_[k++], d.b);
+  }
+  if (!have_vel_)
+    for (auto& p : params_) AGZ_HIP(hipMemsetAsync(p->vel.p, 0, sizeof(float) * p->n, stream_));
+  have_vel_ = true;
+}
+
+// the inverse of upload(), plus the running BatchNorm statistics; marks the inference packs dirty
+void Trainer::download(const std::vector<std::vector<float>>& bn_mean, const std::vector<std::vector<float>>& bn_var, long M) {
+  const int t = net_.tower(), L = 1 + 2 * t;
+  auto get = [&](Param& p, std::vector<float>& h) {
+    h.resize(p.n);
+    AGZ_HIP(hipMemcpyAsync(h.data(), p.theta.p, sizeof(float) * p.n, hipMemcpyDeviceToHost, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
+  };
+  auto running = [&](ConvHost& c, const std::vector<float>& mean, const std::vector<float>& var) {
+    for (int o = 0; o < c.cout; ++o) {
+      c.mean[o] = (1.f - kBnMomentum) * c.mean[o] + kBnMomentum * mean[o];
+      c.var[o] = (1.f - kBnMomentum) * c.var[o] + kBnMomentum * var[o] * (float)((double)M / (double)(M - 1));
+    }
+  };
+  for (int l = 0; l < L; ++l) {
+    ConvHost& c = *net_.conv(l);
+    const int cinp = l == 0 ? kCinStemPad : kC;
+    std::vector<float> w;
+    get(*params_[4 * l + 0], w);
+    for (int o = 0; o < kC; ++o)
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          for (int ci = 0; ci < c.cin; ++ci)
+            c.w[a + 3 * (b + 3 * (ci + (size_t)c.cin * o))] = w[((size_t)o * 9 + (2 - a) + 3 * (2 - b)) * cinp + ci];
+    get(*params_[4 * l + 1], c.b);
+    get(*params_[4 * l + 2], c.gamma);
+    get(*params_[4 * l + 3], c.beta);
+    running(c, bn_mean[l], bn_var[l]);
+  }
+  size_t k = (size_t)4 * L;
+  int hl = L;
+  for (int l : {AGZ_L_VALUE_CONV, AGZ_L_POLICY_CONV}) {
+    ConvHost& c = *net_.conv(l);
+    get(*params_[k++], c.w);
+    get(*params_[k++], c.b);
+    get(*params_[k++], c.gamma);
+    get(*params_[k++], c.beta);
+    running(c, bn_mean[hl], bn_var[hl]);
+    ++hl;
+  }
+  for (int l : {AGZ_L_VALUE_FC1, AGZ_L_VALUE_FC2, AGZ_L_POLICY_FC}) {
+    DenseHost& d = *net_.dense(l);
+    get(*params_[k++], d.w);
+    get(*params_[k++], d.b);
+  }
+  net_.mark_dirty();
+}
+
+void Trainer::step(const float* feats, const float* pi, const float* z, int B, bool is_device, float eta, float rho,
+                   float* losses_out) {
+  AGZ_REQUIRE(B >= 2, AGZ_BAD_ARGUMENT, "a training batch needs at least 2 positions (BatchNorm batch statistics)");
+  AGZ_REQUIRE(feats && pi && z, AGZ_BAD_ARGUMENT, "null pointer");
+  const int N = net_.N(), P = net_.P(), A = net_.A(), t = net_.tower(), L = 1 + 2 * t;
+  const long M = (long)B * P;
+  hipStream_t s = stream_;
+  upload();
+  // ---- workspace
+  const size_t act = (size_t)M * kC;
+  d_x32_.ensure((size_t)M * kCinStemPad);
+  d_u_.ensure(act * L);
+  d_o_.ensure(act * L);
+  d_ga_.ensure(act);
+  d_gb_.ensure(act);
+  d_gc_.ensure(act);
+  d_stats_.ensure((size_t)3 * kC * L + 16);
+  d_sums_.ensure((size_t)2 * kC + 8);
+  d_ones_.ensure(kC);
+  d_wd_.ensure((size_t)kC * 9 * kC);
+  d_small_.ensure((size_t)M * 9 + (size_t)B * (A * 3 + 256 * 2 + 8) + 64);
+  d_in_.ensure((size_t)B * 17 * P + (size_t)B * A + B);
+  d_cnt_.ensure(1);
+  {
+    std::vector<float> ones(kC, 1.f);
+    AGZ_HIP(hipMemcpyAsync(d_ones_.p, ones.data(), sizeof(float) * kC, hipMemcpyHostToDevice, s));
+    AGZ_HIP(hipMemcpyAsync(d_cnt_.p, &B, sizeof(int), hipMemcpyHostToDevice, s));
+    AGZ_HIP(hipStreamSynchronize(s));
+  }
+  const hipMemcpyKind kin = is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  float* d_feats = d_in_.p;
+  float* d_pi = d_feats + (size_t)B * 17 * P;
+  float* d_z = d_pi + (size_t)B * A;
+  AGZ_HIP(hipMemcpyAsync(d_feats, feats, sizeof(float) * (size_t)B * 17 * P, kin, s));
+  AGZ_HIP(hipMemcpyAsync(d_pi, pi, sizeof(float) * (size_t)B * A, kin, s));
+  AGZ_HIP(hipMemcpyAsync(d_z, z, sizeof(float) * (size_t)B, kin, s));
+  launch_whcn_to_x32(d_feats, B, N, d_x32_.p, s);
+  // small buffers
+  float* cv = d_small_.p;                    // [M]
+  float* cp = cv + M;                        // [M][2]
+  float* hv = cp + 2 * M;                    // [M]     relu(BN(cv))
+  float* hp = hv + M;                        // [M][2]  relu(BN(cp))
+  float* dcv = hp + 2 * M;                   // [M]
+  float* dcp = dcv + M;                      // [M][2]  (8 M floats so far)
+  float* d1 = dcp + 2 * M;                   // [B][256] relu(Dense1)
+  float* vout = d1 + (size_t)B * 256;        // [B]
+  float* logits = vout + B;                  // [B][A]
+  float* pout = logits + (size_t)B * A;      // [B][A]
+  float* dlogit = pout + (size_t)B * A;      // [B][A]
+  float* dsv = dlogit + (size_t)B * A;       // [B]
+  float* dd1 = dsv + B;                      // [B][256]
+  double* d_losses = reinterpret_cast<double*>(d_sums_.p) + 2 * kC;       // [4] behind the column sums
+  double* sums = reinterpret_cast<double*>(d_sums_.p);
+  auto zero_sums = [&](int C) { AGZ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s)); };
+  AGZ_HIP(hipMemsetAsync(d_losses, 0, sizeof(double) * 4, s));
+  const int RS = 64;                          // row slices of the column reductions
+
+  auto P4 = [&](int l, int k) -> Param& { return *params_[(size_t)4 * l + k]; };
+  float* stats0 = d_stats_.p;
+  auto U = [&](int l) { return d_u_.p + act * l; };
+  auto O = [&](int l) { return d_o_.p + act * l; };
+  auto ST = [&](int l) { return stats0 + (size_t)3 * kC * l; };
+
+  // ---- forward, training mode
+  auto conv_bn = [&](int l, const float* in, const float* res) {
+    launch_conv3x3_direct(in, P4(l, 0).theta.p, d_ones_.p, P4(l, 1).theta.p, nullptr, U(l), d_cnt_.p, B, N, 0,
+                          l == 0 ? kCinStemPad : kC, s);
+    zero_sums(kC);
+    hipLaunchKernelGGL(k_colsums, dim3(kC / 64, RS), dim3(256), 0, s, (const float*)U(l), M, (int)kC, sums);
+    hipLaunchKernelGGL(k_bn_fwd, g1(M * kC), dim3(256), 0, s, (const float*)U(l), M, (int)kC, (const double*)sums,
+                       (const float*)P4(l, 2).theta.p, (const float*)P4(l, 3).theta.p, net_.conv(l)->eps, res, O(l), 1, ST(l));
+  };
+  conv_bn(0, d_x32_.p, nullptr);
+  for (int blk = 0; blk < t; ++blk) {          // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32
+    conv_bn(1 + 2 * blk, O(2 * blk), nullptr);
+    conv_bn(2 + 2 * blk, O(1 + 2 * blk), O(2 * blk));
+  }
+  const float* xL = O(L - 1);
+  const size_t hk = (size_t)4 * L;             // head parameter slots: vconv w b g be | pconv w b g be | fc...
+  Param &Wv = *params_[hk + 0], &Bv = *params_[hk + 1], &Gv = *params_[hk + 2], &BEv = *params_[hk + 3];
+  Param &Wp = *params_[hk + 4], &Bp = *params_[hk + 5], &Gp = *params_[hk + 6], &BEp = *params_[hk + 7];
+  Param &W1 = *params_[hk + 8], &B1 = *params_[hk + 9], &W2 = *params_[hk + 10], &B2 = *params_[hk + 11];
+  Param &Wf = *params_[hk + 12], &Bf = *params_[hk + 13];
+  float* st_v = stats0 + (size_t)3 * kC * L;   // {mean, var, rstd} of the 1-channel BN
+  float* st_p = st_v + 3;                      // 2-channel BN: {mean[2], var[2], rstd[2]}
+  hipLaunchKernelGGL(k_head1x1_fwd, dim3(256), dim3(256), 0, s, xL, M, (const float*)Wv.theta.p, (const float*)Bv.theta.p,
+                     (const float*)Wp.theta.p, (const float*)Bp.theta.p, cv, cp);
+  zero_sums(2);
+  hipLaunchKernelGGL(k_colsums, dim3(1, RS), dim3(256), 0, s, (const float*)cv, M, 1, sums);
+  hipLaunchKernelGGL(k_bn_fwd, g1(M), dim3(256), 0, s, (const float*)cv, M, 1, (const double*)sums, (const float*)Gv.theta.p,
+                     (const float*)BEv.theta.p, net_.conv(AGZ_L_VALUE_CONV)->eps, (const float*)nullptr, hv, 1, st_v);
+  zero_sums(2);
+  hipLaunchKernelGGL(k_colsums, dim3(1, RS), dim3(256), 0, s, (const float*)cp, M, 2, sums);
+  hipLaunchKernelGGL(k_bn_fwd, g1(M * 2), dim3(256), 0, s, (const float*)cp, M, 2, (const double*)sums,
+                     (const float*)Gp.theta.p, (const float*)BEp.theta.p, net_.conv(AGZ_L_POLICY_CONV)->eps,
+                     (const float*)nullptr, hp, 1, st_p);
+  hipLaunchKernelGGL(k_dense_fwd, dim3(1, B), dim3(256), 0, s, (const float*)hv, 0, P, (const float*)W1.theta.p,
+                     (const float*)B1.theta.p, B, P, 256, 1, d1);
+  hipLaunchKernelGGL(k_dense_fwd, dim3(1, B), dim3(64), 0, s, (const float*)d1, 0, P, (const float*)W2.theta.p,
+                     (const float*)B2.theta.p, B, 256, 1, 2, vout);
+  hipLaunchKernelGGL(k_dense_fwd, dim3((A + 255) / 256, B), dim3(256), 0, s, (const float*)hp, 2, P, (const float*)Wf.theta.p,
+                     (const float*)Bf.theta.p, B, 2 * P, A, 0, logits);
+  hipLaunchKernelGGL(k_outputs, dim3(B), dim3(256), 0, s, (const float*)logits, (const float*)vout, (const float*)d_pi,
+                     (const float*)d_z, B, A, pout, dlogit, dsv, d_losses);
+  for (auto& p : params_)
+    hipLaunchKernelGGL(k_sumsq, dim3(64), dim3(256), 0, s, (const float*)p->theta.p, (long)p->n, d_losses + 2);
+
+  // ---- backward: heads
+  hipLaunchKernelGGL(k_dense_wgrad, g1((long)A * 2 * P), dim3(256), 0, s, (const float*)hp, 2, P, (const float*)dlogit, B, 2 * P,
+                     A, Wf.grad.p, Bf.grad.p);
+  float* dhp = dcp;       // grad wrt hp lands in dcp's storage first, BN backward turns it into dcp in place
+  hipLaunchKernelGGL(k_dense_dgrad, dim3((2 * P + 255) / 256, B), dim3(256), 0, s, (const float*)Wf.theta.p,
+                     (const float*)dlogit, B, 2 * P, A, (const float*)nullptr, 2, P, dhp);
+  hipLaunchKernelGGL(k_dense_wgrad, g1(256), dim3(256), 0, s, (const float*)d1, 0, P, (const float*)dsv, B, 256, 1, W2.grad.p,
+                     B2.grad.p);
+  hipLaunchKernelGGL(k_dense_dgrad, dim3(1, B), dim3(256), 0, s, (const float*)W2.theta.p, (const float*)dsv, B, 256, 1,
+                     (const float*)d1, 0, P, dd1);
+  hipLaunchKernelGGL(k_dense_wgrad, g1((long)256 * P), dim3(256), 0, s, (const float*)hv, 0, P, (const float*)dd1, B, P, 256,
+                     W1.grad.p, B1.grad.p);
+  float* dhv = dcv;
+  hipLaunchKernelGGL(k_dense_dgrad, dim3((P + 255) / 256, B), dim3(256), 0, s, (const float*)W1.theta.p, (const float*)dd1, B, P,
+                     256, (const float*)nullptr, 0, P, dhv);
+  // head BatchNorms (ReLU mask from hv / hp), in place: dhv -> dcv, dhp -> dcp
+  zero_sums(2);
+  hipLaunchKernelGGL(k_bn_bwd_sums, dim3(1, RS), dim3(256), 0, s, (const float*)dhv, (const float*)hv, (const float*)cv,
+                     (const float*)st_v, M, 1, 1, sums);
+  hipLaunchKernelGGL(k_bn_bwd_apply, g1(M), dim3(256), 0, s, (const float*)dhv, (const float*)hv, (const float*)cv,
+                     (const float*)st_v, (const float*)Gv.theta.p, (const double*)sums, M, 1, 1, dcv, (float*)nullptr, Gv.grad.p,
+                     BEv.grad.p);
+  zero_sums(2);
+  hipLaunchKernelGGL(k_bn_bwd_sums, dim3(1, RS), dim3(256), 0, s, (const float*)dhp, (const float*)hp, (const float*)cp,
+                     (const float*)st_p, M, 2, 1, sums);
+  hipLaunchKernelGGL(k_bn_bwd_apply, g1(M * 2), dim3(256), 0, s, (const float*)dhp, (const float*)hp, (const float*)cp,
+                     (const float*)st_p, (const float*)Gp.theta.p, (const double*)sums, M, 2, 1, dcp, (float*)nullptr, Gp.grad.p,
+                     BEp.grad.p);
+  hipLaunchKernelGGL(k_head1x1_wgrad, dim3(1), dim3(256), 0, s, xL, (const float*)dcv, (const float*)dcp, M, Wv.grad.p,
+                     Wp.grad.p, Bv.grad.p, Bp.grad.p);
+  float* g = d_ga_.p;      // gradient wrt the current block output
+  hipLaunchKernelGGL(k_head1x1_dgrad, g1(M * kC), dim3(256), 0, s, (const float*)dcv, (const float*)dcp, (const float*)Wv.theta.p,
+                     (const float*)Wp.theta.p, M, g);
+
+  // ---- backward: tower and stem
+  // BN backward of layer l with upstream `dout` (ReLU mask from O(l)); du -> `du`; dres (optional) gets the masked dout
+  auto bn_back = [&](int l, const float* dout, float* du, float* dres) {
+    zero_sums(kC);
+    hipLaunchKernelGGL(k_bn_bwd_sums, dim3(kC / 64, RS), dim3(256), 0, s, dout, (const float*)O(l), (const float*)U(l),
+                       (const float*)ST(l), M, (int)kC, 1, sums);
+    hipLaunchKernelGGL(k_bn_bwd_apply, g1(M * kC), dim3(256), 0, s, dout, (const float*)O(l), (const float*)U(l),
+                       (const float*)ST(l), (const float*)P4(l, 2).theta.p, (const double*)sums, M, (int)kC, 1, du, dres,
+                       P4(l, 2).grad.p, P4(l, 3).grad.p);
+    zero_sums(kC);
+    hipLaunchKernelGGL(k_colsums, dim3(kC / 64, RS), dim3(256), 0, s, (const float*)du, M, (int)kC, sums);
+    hipLaunchKernelGGL(k_take_sums, dim3(1), dim3(256), 0, s, (const double*)sums, (int)kC, P4(l, 1).grad.p);
+  };
+  auto wgrad = [&](int l, const float* in, const float* du) {
+    const int cinp = l == 0 ? kCinStemPad : kC;
+    hipLaunchKernelGGL(k_wgrad3x3, dim3(kC / 32, 9, cinp / 32), dim3(256), 0, s, in, du, B, N, cinp, P4(l, 0).grad.p);
+  };
+  // dx = conv(du) with Wd[ci][tap'][co] = Wt[co][8 - tap'][ci]
+  d_zero_.ensure(kC);
+  AGZ_HIP(hipMemsetAsync(d_zero_.p, 0, sizeof(float) * kC, s));
+  auto dgrad = [&](int l, const float* du, float* dx) {
+    hipLaunchKernelGGL(k_make_wd, g1((long)kC * 9 * kC), dim3(256), 0, s, (const float*)P4(l, 0).theta.p, d_wd_.p);
+    launch_conv3x3_direct(du, d_wd_.p, d_ones_.p, d_zero_.p, nullptr, dx, d_cnt_.p, B, N, 0, kC, s);
+  };
+  float *du = d_gb_.p, *dsc = d_gc_.p;
+  for (int blk = t - 1; blk >= 0; --blk) {
+    const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+    bn_back(l2, g, du, dsc);                       // through relu(BN2(u2) + x): du2, and the shortcut's share dsc
+    wgrad(l2, O(l1), du);
+    dgrad(l2, du, g);                              // g <- grad wrt relu(BN1(u1))
+    bn_back(l1, g, du, nullptr);
+    wgrad(l1, O(2 * blk), du);
+    dgrad(l1, du, g);                              // g <- grad wrt the block input through the convolutions
+    hipLaunchKernelGGL(k_add, g1(M * kC), dim3(256), 0, s, g, (const float*)dsc, M * kC);
+  }
+  bn_back(0, g, du, nullptr);
+  wgrad(0, d_x32_.p, du);
+
+  // ---- read the losses (as they were before the update), then the optimiser
+  double hl[4];
+  AGZ_HIP(hipMemcpyAsync(hl, d_losses, sizeof(hl), hipMemcpyDeviceToHost, s));
+  // batch statistics for the running-statistics update
+  std::vector<float> hst((size_t)3 * kC * L + 9);
+  AGZ_HIP(hipMemcpyAsync(hst.data(), d_stats_.p, sizeof(float) * hst.size(), hipMemcpyDeviceToHost, s));
+  for (auto& p : params_)
+    hipLaunchKernelGGL(k_momentum, g1((long)p->n), dim3(256), 0, s, p->theta.p, (const float*)p->grad.p, p->vel.p, (long)p->n, eta, rho);
+  AGZ_HIP(hipGetLastError());
+  AGZ_HIP(hipStreamSynchronize(s));
+  if (losses_out) {
+    losses_out[1] = (float)hl[0];
+    losses_out[2] = (float)hl[1];
+    losses_out[3] = (float)((double)kRegW * hl[2]);
+    losses_out[0] = losses_out[1] + losses_out[2] + losses_out[3];
+  }
+  std::vector<std::vector<float>> bm(L + 2), bv(L + 2);
+  for (int l = 0; l < L; ++l) {
+    bm[l].assign(hst.begin() + (size_t)3 * kC * l, hst.begin() + (size_t)3 * kC * l + kC);
+    bv[l].assign(hst.begin() + (size_t)3 * kC * l + kC, hst.begin() + (size_t)3 * kC * l + 2 * kC);
+  }
+  const size_t ho = (size_t)3 * kC * L;
+  bm[L] = {hst[ho + 0]};
+  bv[L] = {hst[ho + 1]};
+  bm[L + 1] = {hst[ho + 3], hst[ho + 4]};
+  bv[L + 1] = {hst[ho + 5], hst[ho + 6]};
+  download(bm, bv, M);
+}
+
+}  // namespace agz

@@ -254,6 +254,21 @@ agz_status agz_replay_clear(agz_engine* e);
 agz_status agz_replay_batch(agz_engine* e, const int64_t* game, const int32_t* ply, int32_t B, float* feats,
                             float* pi, float* z, int32_t out_is_device);
 
+/* ---------------------------------------------------------------- training step --------- */
+/* One optimisation step of `_train` (neural_net.jl:75-101; optimiser Momentum(2f-2), train.jl:54; call
+ * train.jl:67-74) on the network selected by agz_net_select, entirely on the device:
+ *   training-mode forward (BatchNorm normalises with the batch's statistics; its running statistics move by
+ *   momentum 0.1), loss = 0.01 * crossentropy(p, pi) + 0.01 * mse(v, z) + 1e-4 * sum(theta^2), backward,
+ *   vel = rho * vel - eta * grad; theta += vel for every parameter (Flux Momentum: eta 0.02, rho 0.9).
+ * `_train` does not run at the reference's HEAD; this is its intended step, pinned against a
+ * float64 autograd twin.  feats float[B][N*N*17] (agz_features / agz_replay_batch order), pi float[B][A],
+ * z float[B]: three host pointers, or three device pointers when inputs_are_device != 0 (the outputs of
+ * agz_replay_batch with out_is_device).  losses_out float[4] = {total, policy, value, regulariser} BEFORE the
+ * update; may be NULL.  B >= 2.  The optimiser state lives in the engine until agz_train_reset. */
+agz_status agz_train_step(agz_engine* e, const float* feats, const float* pi, const float* z, int32_t B,
+                          int32_t inputs_are_device, float eta, float rho, float* losses_out);
+agz_status agz_train_reset(agz_engine* e);
+
 /* The one exchange step of the path: RCCL over xGMI, one rank per GPU.  Rank 0 calls
  * agz_comm_unique_id and hands the 128 bytes to the other ranks by whatever means the host has (Julia:
  * Distributed / a shared file; Python: torch.distributed / gloo); every rank then calls agz_comm_create with

@@ -1,0 +1,83 @@
+"""agz_train_step (the training step of /root/reference/src/neural_net.jl:75-101 on the
+device) against the float64 autograd twin tests/train_twin.py.  The reference cannot run this step (it is
+broken at HEAD), so the twin is the pin; the twin itself is tied to the pinned oracle by its
+inference-mode forward (tests/test_train_twin.py, CPU).
+
+Bars: losses within 1e-5 relative; every parameter's update (theta_new - theta_old) within 2e-3 of the largest
+update of its tensor (f32 sums of up to B*P = 486 terms against float64), BatchNorm running statistics 1e-5."""
+import numpy as np
+import pytest
+
+import alphago_jl_amd as ag
+import orc
+from test_hostsim_go import random_positions
+from train_twin import K_MEAN, K_VAR, Twin
+
+pytestmark = pytest.mark.gpu
+
+
+def batch(N, B, seed):
+    rng = np.random.RandomState(seed)
+    positions = random_positions(N, 3, 40, seed=seed)
+    positions = [positions[i] for i in rng.choice(len(positions), B, replace=False)]
+    feats = np.stack([orc.feats(p).reshape(-1) for p in positions]).astype(np.float32)
+    pi = rng.dirichlet(np.full(N * N + 1, 0.3), size=B).astype(np.float32)
+    pi[0, : N] = 0.0                                   # exact zeros in a target are legal (0 * log p = 0)
+    pi[0] /= pi[0].sum()
+    z = rng.choice([-1.0, 1.0], size=B).astype(np.float32)
+    return feats, pi, z
+
+
+@pytest.mark.parametrize("N,tower,B", [(5, 1, 8), (9, 2, 6)])
+def test_train_step_matches_float64_twin(N, tower, B):
+    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    eng.init_synthetic(7)
+    rng = np.random.RandomState(1)
+    for l in list(range(1 + 2 * tower)) + [-1, -2]:    # non-trivial biases / BatchNorm parameters
+        n = eng.param_count(l, 1)
+        eng.set_weights(l, 1, rng.uniform(-0.2, 0.2, n).astype(np.float32))
+        eng.set_weights(l, 2, rng.uniform(-0.3, 0.3, n).astype(np.float32))
+        eng.set_weights(l, 3, rng.uniform(0.5, 1.5, n).astype(np.float32))
+    twin = Twin(N, tower, eng.get_weights)
+    before = {key: eng.get_weights(*key).copy() for key in eng.layers()}
+    for it in range(2):                                # the second step exercises the Momentum velocity
+        feats, pi, z = batch(N, B, 10 + it)
+        got = eng.train_step(feats, pi, z)
+        want = twin.step(feats, pi, z)
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-9), (it, got, want)
+        for (l, k) in eng.layers():
+            new = eng.get_weights(l, k)
+            if k == 6:
+                continue
+            ref = twin.param(l, k)
+            if k in (K_MEAN, K_VAR):
+                assert np.allclose(new, ref, rtol=1e-5, atol=1e-6), (it, l, k)
+                continue
+            upd, upd_ref = new.astype(np.float64) - before[(l, k)], ref - before[(l, k)]
+            scale = np.abs(upd_ref).max()
+            assert np.abs(upd - upd_ref).max() <= 2e-3 * scale + 1e-9, (it, l, k, np.abs(upd - upd_ref).max(), scale)
+    # the step really moved the network, and inference now runs with the new parameters
+    assert any(np.abs(eng.get_weights(*key) - before[key]).max() > 0 for key in eng.layers() if key[1] == 0)
+    feats, _, _ = batch(N, B, 99)
+    gpi, gv = eng.forward_features(feats)
+    with np.errstate(all="ignore"):
+        import torch
+        logp, v = twin.forward(feats, False)
+    assert np.abs(gpi - np.exp(logp.detach().numpy())).max() <= 1e-4 and np.abs(gv - v.detach().numpy()).max() <= 1e-4
+    eng.close()
+
+
+def test_train_step_argument_checks_and_reset():
+    eng = ag.Engine(board_size=5, games=1, tower_height=1, num_readouts=8, max_nodes_per_game=16)
+    eng.init_synthetic(0)
+    feats, pi, z = batch(5, 4, 3)
+    with pytest.raises(ag.AgzError):
+        eng.train_step(feats[:1], pi[:1], z[:1])       # BatchNorm needs a batch
+    a = eng.train_step(feats, pi, z)
+    w1 = eng.get_weights(1, 0).copy()
+    eng.train_reset()
+    eng.init_synthetic(0)
+    b = eng.train_step(feats, pi, z)                   # same start, fresh optimiser: the same step
+    assert (a == b).all() and (eng.get_weights(1, 0) == w1).all()
+    assert a[0] == pytest.approx(a[1] + a[2] + a[3], rel=1e-6) and a[3] > 0
+    eng.close()
