@@ -4,7 +4,9 @@ broken at HEAD), so the twin is the pin; the twin itself is tied t
 inference-mode forward (tests/test_train_twin.py, CPU).
 
 Bars: losses within 1e-5 relative; every parameter's update (theta_new - theta_old) within 2e-3 of the largest
-update of its tensor (f32 sums of up to B*P = 486 terms against float64), BatchNorm running statistics 1e-5."""
+update of its tensor (f32 sums of up to B*P = 486 terms against float64) plus two f32 ulps of the parameter (a conv
+bias in front of a BatchNorm has no data gradient: its update is weight decay only, ~1e-6, below one ulp of
+2e-3 x that), BatchNorm running statistics 1e-5."""
 import numpy as np
 import pytest
 
@@ -55,7 +57,8 @@ def test_train_step_matches_float64_twin(N, tower, B):
                 continue
             upd, upd_ref = new.astype(np.float64) - before[(l, k)], ref - before[(l, k)]
             scale = np.abs(upd_ref).max()
-            assert np.abs(upd - upd_ref).max() <= 2e-3 * scale + 1e-9, (it, l, k, np.abs(upd - upd_ref).max(), scale)
+            ulp = 2.0 ** -23 * max(np.abs(ref).max(), 1e-30)        # the parameter itself is stored in f32
+            assert np.abs(upd - upd_ref).max() <= 2e-3 * scale + 2 * ulp, (it, l, k, np.abs(upd - upd_ref).max(), scale)
     # the step really moved the network, and inference now runs with the new parameters
     assert any(np.abs(eng.get_weights(*key) - before[key]).max() > 0 for key in eng.layers() if key[1] == 0)
     feats, _, _ = batch(N, B, 99)

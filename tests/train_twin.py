@@ -67,7 +67,7 @@ class Twin:
             for (key, t), g in zip(self.th.items(), grads):
                 self.vel[key] = rho * self.vel[key] - eta * g
                 t += self.vel[key]
-        return float(loss), float(lp), float(lv), float(lr)
+        return float(loss.detach()), float(lp.detach()), float(lv.detach()), float(lr.detach())
 
     def param(self, layer, kind):
         if kind == K_MEAN:
