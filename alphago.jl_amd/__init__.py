@@ -11,6 +11,7 @@ from .api import (BLACK, EMPTY, WHITE, GameRecord, GoEnv, MCTSPlayer, NeuralNet,
                   evaluate, extract_data, from_flat, from_kgs, from_sgf, get_feats, load_model, save_model, selfplay, to_flat,
                   to_kgs, to_sgf)
 from . import bson_weights
+from . import distributed
 from .replay import ReplayBuffer
 
 __all__ = ["Engine", "comm_unique_id", "AgzError", "IllegalMove", "load", "_lib", "GoEnv", "Position", "PlayerMove", "NeuralNet",

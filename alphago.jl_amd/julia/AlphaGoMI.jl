@@ -511,4 +511,66 @@ function get_replay_batch(e::Engine, env::GoEnv, games::Vector{GameRecord}, samp
   feats, π, [games[g].result for (g, _) in samples]
 end
 
+# ---- replay arena, RCCL exchange and the training step (train.jl:47-74; SURVEY.md 8e, 8f rows 1 and 4)
+# Every rank's finished games are all-gathered by libagz itself (RCCL over xGMI, device to device) into a
+# device-resident replay arena; (game, ply) samples become (features, pi, z) on the device; one call is one
+# optimisation step of _train.  The 128-byte communicator id is generated on rank 0 and handed to the other
+# ranks by the host (Distributed.jl, MPI.jl, a shared file -- the library does not care).
+
+comm_unique_id() = (id = zeros(UInt8, 128);
+                    st = ccall((:agz_comm_unique_id, libagz), Int32, (Ptr{UInt8},), id);
+                    st == AGZ_OK || error("libagz status $st: " * unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), C_NULL)));
+                    id)
+
+function comm_create(e::Engine, rank::Integer, world::Integer, id::Vector{UInt8})
+  c = Ref{Ptr{Cvoid}}(C_NULL)
+  check(e, ccall((:agz_comm_create, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+                 e.handle, rank, world, id, c))
+  c[]
+end
+comm_destroy(c::Ptr{Cvoid}) = ccall((:agz_comm_destroy, libagz), Cvoid, (Ptr{Cvoid},), c)
+
+# push_data.(buffers, extract_data(player)) for the games of EVERY rank (train.jl:57-62); comm = C_NULL on one GPU
+function allgather_records!(e::Engine, comm::Ptr{Cvoid} = C_NULL)
+  added = Ref{Int64}(0)
+  check(e, ccall((:agz_allgather_records, libagz), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}), e.handle, comm, added))
+  check(e, ccall((:agz_records_clear, libagz), Int32, (Ptr{Cvoid},), e.handle))
+  added[]
+end
+broadcast_weights!(e::Engine, comm::Ptr{Cvoid}, root::Integer = 0) =
+  check(e, ccall((:agz_broadcast_weights, libagz), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Int64}), e.handle, comm, root, C_NULL))
+
+replay_games(e::Engine) = ccall((:agz_replay_count, libagz), Int64, (Ptr{Cvoid},), e.handle)
+replay_positions(e::Engine) = ccall((:agz_replay_positions, libagz), Int64, (Ptr{Cvoid},), e.handle)     # length(pos_buffer)
+replay_trim!(e::Engine, memory_size::Integer) =                                                         # shrink, train.jl:52
+  check(e, ccall((:agz_replay_trim, libagz), Int32, (Ptr{Cvoid}, Int64), e.handle, memory_size))
+function replay_game_lengths(e::Engine)
+  h = Ref{AgzGameHeader}()
+  [begin
+     check(e, ccall((:agz_replay_header, libagz), Int32, (Ptr{Cvoid}, Int64, Ref{AgzGameHeader}), e.handle, k, h))
+     Int(h[].num_moves)
+   end for k in 0:replay_games(e)-1]
+end
+
+# get_replay_batch (train.jl:4-12): `games`/`plies` are 0-based (game index in the arena, move number);
+# returns (feats N*N*17 x B, pi A x B, z B) -- column-major, i.e. exactly what `_train` consumes
+function replay_batch(e::Engine, env::GoEnv, games::Vector{Int64}, plies::Vector{Int32})
+  B = length(games)
+  feats = zeros(Float32, env.N * env.N * 17, B); pi = zeros(Float32, env.action_space, B); z = zeros(Float32, B)
+  check(e, ccall((:agz_replay_batch, libagz), Int32,
+                 (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32),
+                 e.handle, games, plies, B, feats, pi, z, 0))
+  feats, pi, z
+end
+
+# _train(nn, (positions, pi, z), Momentum(2f-2)) for one batch (neural_net.jl:85-101): returns
+# (total, policy, value, regulariser) losses before the update
+function train_step!(e::Engine, feats::Matrix{Float32}, pi::Matrix{Float32}, z::Vector{Float32}; eta = 0.02f0, rho = 0.9f0)
+  losses = zeros(Float32, 4)
+  check(e, ccall((:agz_train_step, libagz), Int32,
+                 (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, Int32, Float32, Float32, Ptr{Float32}),
+                 e.handle, feats, pi, z, length(z), 0, eta, rho, losses))
+  Tuple(losses)
+end
+
 end # module

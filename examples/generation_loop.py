@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""One generation of the reference's train() loop (src/train.jl:38-92) with everything except the
-optimiser step on the MI355X: self-play -> replay buffer -> training batches -> arena -> checkpoint.
+"""One generation of the reference's train() loop (src/train.jl:38-92) on the MI355X:
+self-play -> replay arena -> training batches -> optimiser step -> arena match -> checkpoint.
 
     python examples/generation_loop.py [--board 9] [--tower 2] [--games 32] [--readouts 64]
 
 What runs where:
   selfplay          G concurrent games on the device (one wave per tree, one network batch per step)
   extract_data      finished games come back as (moves, pi, result); multi-GPU: all-gathered over RCCL
-  get_replay_batch  ReplayBuffer samples (game, ply) pairs; the device replays the move lists and writes
-                    the N x N x 17 x B feature tensor straight into a CUDA tensor
-  _train            NOT here: the batch is handed to a stub
+  get_replay_batch  (game, ply) pairs are sampled on the host; the device replays the move lists of the replay
+                    arena and emits the N x N x 17 x B feature tensor, pi and z (agz_replay_batch)
+  _train            agz_train_step: training-mode forward, 0.01 CE + 0.01 MSE + 1e-4 L2, backward, Momentum(0.02)
   evaluate          candidate vs incumbent, both networks resident in one arena engine
   save_model        BSON parameter lists readable by Flux.loadparams!
 """
@@ -24,11 +24,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402  (before the engine: one HIP runtime per process)
 
 import alphago_jl_amd as ag  # noqa: E402
-
-
-def train_stub(feats, pi, z):
-    """where _train(cur_nn, (pos, pi, res), opt) would go: loss = 0.01 CE + 0.01 MSE + 1e-4 L2"""
-    return float(feats.float().mean().item()), pi.shape, z.shape
 
 
 def main(argv=None):
@@ -54,8 +49,22 @@ def main(argv=None):
 
     B = min(args.batch_size, len(buf))
     feats = torch.empty((B, 17 * env.N * env.N), dtype=torch.float32, device="cuda")
-    _, pi, z = buf.sample(B, np.random.default_rng(0), cur.engine, out=feats)
-    print("training batch:", train_stub(feats, pi, z))
+    _, pi, z = buf.sample(B, np.random.default_rng(0), cur.engine, out=feats)       # host-side buffer, device replay
+    # the same through the device replay arena + the training step (train.jl:56-70)
+    eng = cur.engine
+    eng.replay_ingest(ag.distributed.pack_records(
+        [dict(game_id=r.game_id, result=r.result, was_resign=r.was_resign, moves=[ag.to_flat(c, env) for c in r.moves],
+              pis=r.searches_pi, qs=r.qs) for r in records], env.action_space))
+    rng = np.random.default_rng(1)
+    lens = np.array([eng.replay_record(k)["num_moves"] for k in range(eng.replay_count())])
+    losses = []
+    for it in range(3):
+        flat = rng.choice(int(lens.sum()), size=B, replace=False)                 # sample(1:n, B, replace=false)
+        game = np.searchsorted(np.cumsum(lens), flat, side="right")
+        ply = flat - (np.cumsum(lens) - lens)[game]
+        f, p, zz = eng.replay_batch(game, ply)
+        losses.append(eng.train_step(f, p, zz)[0])
+    print("training: loss", " -> ".join(f"{x:.5f}" for x in losses))
 
     ok, st = ag.evaluate(env, cur, prev, num_games=args.eval_games, ro=args.readouts, seed=2, return_stats=True)
     print(f"evaluate: Black (candidate) won {st.games_won}/{st.num_games} -> {'keep' if ok else 'revert'}")
