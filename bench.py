@@ -200,36 +200,6 @@ def main():
     eng.profile_conv(False)
     s1 = eng.stats()
 
-    # The one exchange step of the path (SURVEY.md 8e), outside the timed region: every rank's finished records
-    # are all-gathered into every rank's device replay arena by libagz itself (agz_allgather_records: RCCL over
-    # xGMI, device to device).  torch.distributed only carries the 128-byte RCCL unique id to the other ranks.
-    exchange = None
-    if dist is not None and not args.single_device_test:
-        # RCCL prints a version banner on stdout when a communicator is created; stdout must carry exactly one
-        # JSON line, so the exchange leg runs with fd 1 pointed at stderr
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            ids = [ag.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = eng.comm_create(rank, world, ids[0])
-            barrier()
-            e0 = time.perf_counter()
-            added = eng.allgather_records(comm)
-            eng.sync()
-            e1 = time.perf_counter()
-            exchange = {"collective": "agz_allgather_records (count exchange + padded ncclAllGather, device to device)",
-                        "games_in_arena": added, "positions_in_arena": eng.replay_positions(),
-                        "ms": 1e3 * (e1 - e0), "own_games": eng.records_count()}
-            eng.comm_destroy(comm)
-        except Exception as ex:      # the exchange leg must never take the self-play number down with it
-            exchange = {"error": str(ex)}
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
-
     elapsed = t1 - t0
     d = {k: s1[k] - s0[k] for k in ("positions", "evals", "duplicate_evals", "terminal_visits", "root_visits",
                                     "games_finished", "steps")}
@@ -241,6 +211,48 @@ def main():
                          device=rdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         d["positions"], d["evals"], d["root_visits"], d["games_finished"] = [float(x) for x in c.tolist()]
+    # The one exchange step of the path (SURVEY.md 8e), outside the timed region: every rank's finished records
+    # are all-gathered into every rank's device replay arena by libagz itself (agz_allgather_records: RCCL over
+    # xGMI, device to device).  torch.distributed only carries the 128-byte RCCL unique id to the other ranks.
+    exchange = None
+    if dist is not None and not args.single_device_test:
+        # RCCL prints a version banner on stdout when a communicator is created; stdout must carry exactly one
+        # JSON line, so the exchange leg runs with fd 1 pointed at stderr.  It also runs on a watchdog: a
+        # collective that never completes (a rank missing, a fabric problem) must not swallow the self-play number.
+        import threading
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        box = {}
+
+        def _exchange():
+            try:
+                ids = [ag.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                comm = eng.comm_create(rank, world, ids[0])
+                barrier()
+                e0 = time.perf_counter()
+                added = eng.allgather_records(comm)
+                eng.sync()
+                e1 = time.perf_counter()
+                box["ok"] = {"collective": "agz_allgather_records (count exchange + padded ncclAllGather, device to device)",
+                             "games_in_arena": added, "positions_in_arena": eng.replay_positions(),
+                             "ms": 1e3 * (e1 - e0), "own_games": eng.records_count()}
+                eng.comm_destroy(comm)
+            except Exception as ex:      # the exchange leg must never take the self-play number down with it
+                box["err"] = str(ex)
+
+        th = threading.Thread(target=_exchange, daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        exchange_hung = th.is_alive()
+        exchange = box.get("ok") or {"error": box.get("err", "timed out after 120 s")}
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    else:
+        exchange_hung = False
+
     if s1["pool_exhausted"]:
         raise SystemExit("node pool exhausted during the benchmark: results invalid")
 
@@ -307,6 +319,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
+    if exchange_hung:          # a stuck collective also blocks engine teardown: the line is out, leave
+        sys.stdout.flush()
+        os._exit(0)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
