@@ -152,8 +152,8 @@ agz_status agz_net_set_winograd(agz_engine* e, int32_t on) {
 }
 agz_status agz_net_set_precision(agz_engine* e, int32_t precision) {
   return guard(e, [&](agz::Engine& E) {
-    AGZ_REQUIRE(precision == AGZ_PRECISION_F32 || precision == AGZ_PRECISION_F16, AGZ_BAD_ARGUMENT,
-                "precision %d (0 = f32, 1 = f16 tower)", precision);
+    AGZ_REQUIRE(precision == AGZ_PRECISION_F32 || precision == AGZ_PRECISION_F16 || precision == AGZ_PRECISION_F32S,
+                AGZ_BAD_ARGUMENT, "precision %d (0 = f32, 1 = f16 tower, 2 = f32 as split f16 operands)", precision);
     E.net().set_precision(precision);
   });
 }

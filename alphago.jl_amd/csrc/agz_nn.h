@@ -50,7 +50,8 @@ class Net {
   void set_winograd(bool on) { winograd_ = on; }
   bool winograd() const { return winograd_; }
   // tower arithmetic: 0 = exact f32 (default), 1 = fp16 operands / f32 accumulate (agz_conv16.hip)
-  void set_precision(int p) { precision_ = p; dirty_ = dirty_ || p == 1; }
+  // 2 = exact-f32 network with the Winograd operands carried as two f16 halves (agz_wino.hip, split form)
+  void set_precision(int p) { precision_ = p; dirty_ = dirty_ || p == 1 || p == 2; }
   int precision() const { return precision_; }
 
   // HIP-event timing of every tower-conv launch inside forward() (bench.py roofline leg)
@@ -86,6 +87,8 @@ class Net {
   int bcap_ = 0;
   DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
   bool winograd_ = true;
+  DevBuf<float> d_uwino_s_, d_scale_s_;        // split form: weights as halves, scale x 1 / (operand scales)
+  bool packed_split_ = false;
   DevBuf<float> d_uwino_, d_vimg_, d_vimg2_;   // transformed weights (stage images) / transformed activations (ping-pong)
   int precision_ = 0;
   bool packed16_ = false;
@@ -134,11 +137,14 @@ size_t wino_weight_floats();
 size_t wino_v_floats(int bcap, int T);
 // x -> V (the 25 transformed planes as GEMM stage images); needed in front of the first Winograd layer, and
 // in front of every layer when the board's tiles do not pack into whole-board tile blocks (!wino_fusable)
-void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s);
+void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s);
 // V, U -> y (if y != NULL: affine, residual, ReLU applied) and / or the NEXT layer's V (if vnext != NULL)
 void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
-                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s);
+                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s);
 bool wino_fusable(int N);
+// split-operand form (AGZ_PRECISION_F32S): weights as (hi, lo) halves of 2^10 u; 1 / (operand scales) for the epilogue
+void wino_pack_weights_split(const ConvHost& c, float* out);
+float wino_split_descale();
 
 // fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged
 void conv16_pack_images(const ConvHost& c, uint16_t* out);

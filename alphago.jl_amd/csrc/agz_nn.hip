@@ -472,6 +472,22 @@ static void bn_affine(const ConvHost& c, float* scale, float* shift) {
 }
 
 void Net::pack() {
+  if (precision_ == 2 && tower_ > 0 && (dirty_ || !packed_split_)) {
+    const size_t uper = wino_weight_floats();
+    std::vector<float> u(uper * 2 * tower_);
+    for (int l = 0; l < 2 * tower_; ++l) wino_pack_weights_split(tconv_[l], u.data() + uper * l);
+    d_uwino_s_.ensure(u.size());
+    AGZ_HIP(hipMemcpyAsync(d_uwino_s_.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    std::vector<float> sc((size_t)2 * tower_ * kC), tmp(kC);
+    for (int l = 0; l < 2 * tower_; ++l) {
+      bn_affine(tconv_[l], sc.data() + (size_t)l * kC, tmp.data());
+      for (int o = 0; o < kC; ++o) sc[(size_t)l * kC + o] *= wino_split_descale();        // a power of two: exact
+    }
+    d_scale_s_.ensure(sc.size());
+    AGZ_HIP(hipMemcpyAsync(d_scale_s_.p, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
+    packed_split_ = true;
+  }
   if (!dirty_ && (precision_ != 1 || packed16_)) return;
   if (precision_ == 1 && tower_ > 0 && (dirty_ || !packed16_)) {
     const size_t iper = conv16_image_halves();
@@ -484,6 +500,7 @@ void Net::pack() {
   }
   if (!dirty_) return;
   if (precision_ != 1) packed16_ = false;
+  if (precision_ != 2) packed_split_ = false;
   const int L = 1 + 2 * tower_;
   std::vector<float> scale((size_t)L * kC), shift((size_t)L * kC);
   {
@@ -612,6 +629,9 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
     a = b;     // the heads read the f32 output of the last block
   } else {
     const size_t per = (size_t)kC * 9 * kC, uper = wino_weight_floats();
+    const bool split = precision_ == 2 && winograd_;
+    const float* usrc = split ? d_uwino_s_.p : d_uwino_.p;
+    if (split) sc = d_scale_s_.p;
     if (winograd_ && wino_fusable(N_)) {
       // Winograd with the input transform of layer l+1 fused into the GEMM of layer l: only the first layer needs
       // k_wino_in; conv1 of a block leaves nothing but V in HBM, conv2 leaves the block output (the next residual,
@@ -621,13 +641,13 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         const int l1 = 2 * blk, l2 = 2 * blk + 1;
         const bool last = blk + 1 == tower_;
         timed([&] {
-          if (blk == 0) launch_wino_in(a, vcur, d_count, bcap, N_, stream_);
-          launch_wino_gemm(vcur, d_uwino_.p + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, nullptr, vnxt,
-                           d_count, bcap, N_, 1, stream_);
+          if (blk == 0) launch_wino_in(a, vcur, d_count, bcap, N_, split, stream_);
+          launch_wino_gemm(vcur, usrc + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, nullptr, vnxt,
+                           d_count, bcap, N_, 1, split, stream_);
         });
         timed([&] {
-          launch_wino_gemm(vnxt, d_uwino_.p + uper * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, a, b,
-                           last ? nullptr : vcur, d_count, bcap, N_, 1, stream_);
+          launch_wino_gemm(vnxt, usrc + uper * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, a, b,
+                           last ? nullptr : vcur, d_count, bcap, N_, 1, split, stream_);
         });
         std::swap(a, b);
       }
@@ -635,9 +655,9 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       auto conv = [&](int l, const float* in, const float* res, float* out) {
         timed([&] {
           if (winograd_) {
-            launch_wino_in(in, d_vimg_.p, d_count, bcap, N_, stream_);
-            launch_wino_gemm(d_vimg_.p, d_uwino_.p + uper * l, sc + (size_t)l * kC, sh + (size_t)l * kC, res, out, nullptr,
-                             d_count, bcap, N_, 1, stream_);
+            launch_wino_in(in, d_vimg_.p, d_count, bcap, N_, split, stream_);
+            launch_wino_gemm(d_vimg_.p, usrc + uper * l, sc + (size_t)l * kC, sh + (size_t)l * kC, res, out, nullptr,
+                             d_count, bcap, N_, 1, split, stream_);
           } else {
             hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, in, d_wtower_.p + per * l,
                                sc + (size_t)l * kC, sh + (size_t)l * kC, res, out, d_count, N_, 1);
@@ -702,13 +722,15 @@ void Net::launch_tower_conv_once(const int* d_count, int bcap) {
   if (precision_ == 1)
     launch_conv16_dma(d_ha_.p, d_wi16_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, 0, d_ht_.p, 0, d_count, bcap, N_, 1,
                       stream_);
-  else if (winograd_ && wino_fusable(N_))     // a steady-state tower layer: residual in, y and the next V out
-    launch_wino_gemm(d_vimg_.p, d_uwino_.p, d_scale_.p + kC, d_shift_.p + kC, d_a_.p, d_t_.p, d_vimg2_.p, d_count, bcap,
-                     N_, 1, stream_);
-  else if (winograd_) {
-    launch_wino_in(d_a_.p, d_vimg_.p, d_count, bcap, N_, stream_);
-    launch_wino_gemm(d_vimg_.p, d_uwino_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, d_t_.p, nullptr, d_count, bcap, N_, 1,
-                     stream_);
+  else if (winograd_ && wino_fusable(N_)) {   // a steady-state tower layer: residual in, y and the next V out
+    const bool split = precision_ == 2;
+    launch_wino_gemm(d_vimg_.p, split ? d_uwino_s_.p : d_uwino_.p, split ? d_scale_s_.p : d_scale_.p + kC, d_shift_.p + kC,
+                     d_a_.p, d_t_.p, d_vimg2_.p, d_count, bcap, N_, 1, split, stream_);
+  } else if (winograd_) {
+    const bool split = precision_ == 2;
+    launch_wino_in(d_a_.p, d_vimg_.p, d_count, bcap, N_, split, stream_);
+    launch_wino_gemm(d_vimg_.p, split ? d_uwino_s_.p : d_uwino_.p, split ? d_scale_s_.p : d_scale_.p + kC, d_shift_.p + kC,
+                     nullptr, d_t_.p, nullptr, d_count, bcap, N_, 1, split, stream_);
   }
   else
   hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)d_a_.p,

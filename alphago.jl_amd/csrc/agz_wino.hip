@@ -68,6 +68,27 @@ __host__ __device__ __forceinline__ int wino_v_off(int xi, int row, int h) {    
   return (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4) + row * 4 + 2 * ((h + (row >> 4)) & 1);
 }
 
+// ---- the split-operand form (AGZ_PRECISION_F32S): every f32 operand x travels as two IEEE halves, hi = half(s x),
+// lo = half(s x - hi) (s a power of two: 2^3 for V, 2^10 for U, taken out again exactly in the epilogue's scale), and
+// one v_mfma_f32_32x32x16_f16 per plane and 4-channel stage forms all four cross products in f32:
+//   A lanes 0-31 (k 0..7) = lanes 32-63 (k 8..15) = [a_hi c0..c3 | a_lo c0..c3]
+//   B lanes 0-31          = [b_hi | b_hi],   B lanes 32-63 = [b_lo | b_lo]
+//   => sum_k A_k B_k = sum_c (a_hi + a_lo)(b_hi + b_lo): products of halves are exact in f32, operands carry 22
+// mantissa bits instead of 24.  A stage image keeps its size (16 B per plane and row = 4 channels x 2 halves), so
+// the LDS-DMA stream, the buffers and the epilogue are those of the f32 form; the matrix pipe does 32 cycles per
+// plane-stage instead of 128, and the layer becomes bound by moving V (7 GB per layer) instead of by MFMA.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr float kSplitV = 8.f, kSplitU = 1024.f;
+__host__ __device__ __forceinline__ void split_half(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+// V (split): [plane pair][parity][tile row][hi c0..c3 | lo c0..c3], read whole (ds_read_b128): dword offset of a row
+__host__ __device__ __forceinline__ int wino_vs_off(int xi, int row) { return (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4) + row * 4; }
+// U (split): the same rows with the hi / lo blocks swapped when bit 4 of the cout row is set (wino_v_off with
+// h = 0 for hi, 1 for lo): lanes 0-31 read hi and lanes 32-63 lo with one conflict-free ds_read_b64
+
 // rows of a 64-row tile block that carry tiles: whole boards when a board's tiles pack into 64 rows with
 // <= 10 % waste (N <= 12: T*T = 1, 4, 9, 16 -> 64, 64, 63, 64 rows), else dense packing
 __host__ __device__ inline int wino_rows_per_block(int T) {
@@ -93,7 +114,7 @@ __device__ __forceinline__ void bt5(float x0, float x1, float x2, float x3, floa
 // chunks of 32 rows x 16 B) and leave for HBM as whole 512-byte runs, 16 B per lane.  The LDS copies of the four
 // stages are skewed by 8 dwords each: a ds_write_b64 is served 16 lanes (2 tiles x 8 lanes) at a time over 32
 // banks, and with that skew the 16 lanes cover all 32 banks exactly once.
-template <int TPB, bool NT>
+template <int TPB, bool NT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T) {
   static_assert(TPB == 32, "the copy-out below moves 32-row chunks");
@@ -124,9 +145,11 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
       const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
       off[u * 5 + v] = ok ? (b * P + pi + N * pj) * kC : -1;
     }
-  float* mine = img + sl * IMG + tl * 4 + 2 * ((h + (row >> 4)) & 1);
+  // f32 form: this thread's channel pair is an 8-byte slot of the row; split form: two 4-byte slots (hi pair, lo pair)
+  float* mine = img + sl * IMG + tl * 4 + (SPLIT ? 0 : 2 * ((h + (row >> 4)) & 1));
   // the unused plane slot 25 (chunk 25) is copied out with the rest: keep it finite
-  *reinterpret_cast<float2*>(mine + 25 * CH) = make_float2(0.f, 0.f);
+  if (SPLIT) { mine[25 * CH + h] = 0.f; mine[25 * CH + 2 + h] = 0.f; }
+  else *reinterpret_cast<float2*>(mine + 25 * CH) = make_float2(0.f, 0.f);
   float* gdst = vimg + (long)tb * WNS * A_STAGE + part * CH;
   const int cq = threadIdx.x / TPB, cl = threadIdx.x % TPB;      // copy-out: 8 chunks per round, 32 lanes each
   for (int sg = 0; sg < WNS / SP; ++sg) {
@@ -154,7 +177,18 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
       bt5(tx[i * 5 + 0], tx[i * 5 + 1], tx[i * 5 + 2], tx[i * 5 + 3], tx[i * 5 + 4], rx);
       bt5(ty[i * 5 + 0], ty[i * 5 + 1], ty[i * 5 + 2], ty[i * 5 + 3], ty[i * 5 + 4], ry);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) *reinterpret_cast<float2*>(mine + (i * 5 + j) * CH) = make_float2(rx[j], ry[j]);
+      for (int j = 0; j < 5; ++j) {
+        if (SPLIT) {
+          _Float16 xh, xl, yh, yl;
+          split_half(kSplitV * rx[j], xh, xl);
+          split_half(kSplitV * ry[j], yh, yl);
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<h2*>(mine + (i * 5 + j) * CH + h) = (h2){xh, yh};
+          *reinterpret_cast<h2*>(mine + (i * 5 + j) * CH + 2 + h) = (h2){xl, yl};
+        } else {
+          *reinterpret_cast<float2*>(mine + (i * 5 + j) * CH) = make_float2(rx[j], ry[j]);
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -226,7 +260,7 @@ constexpr int IMG_FLOATS = WT * 9 * WC;          // 147,456 B
 // X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
 //   1 = K loop only; 2 = no epilogue 2; 3 = epilogue 2 without its global stores; 4 = no DMA after the prologue;
 //   5 = no MFMA; 6 = no LDS operand reads
-template <int MODE, int X = 0>
+template <int MODE, int X = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
@@ -284,11 +318,23 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   const int aoff[2] = {wino_v_off(0, arow, hi), wino_v_off(1, arow, hi)};
   const int boff[2] = {A_STAGE + brow * 8 + 2 * ((hi + brot) & 3), A_STAGE + brow * 8 + 2 * ((2 + hi + brot) & 3)};
   constexpr int LA = 4, RING = LA + 1;     // 25 % RING == 0: ring slots are compile-time within a stage
-  float2 ra[RING], rb[RING];
-  auto load = [&](const float* L, int xi, float2& a, float2& b) {
-    if (X == 6) { a = make_float2(1.f, (float)lane); b = make_float2(2.f, (float)xi); return; }
-    a = *reinterpret_cast<const float2*>(L + aoff[xi & 1] + (xi >> 1) * (WT * 8));
-    b = *reinterpret_cast<const float2*>(L + boff[xi & 1] + (xi >> 1) * (WC * 8));
+  // operands of a plane: f32 form a float2 of A and of B (the lane's two channels); split form the whole 16-byte
+  // A row (hi and lo halves of 4 channels) and the lane's 8-byte hi or lo block of B
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef typename std::conditional<SPLIT, f32x4, float2>::type a_t;
+  a_t ra[RING];
+  float2 rb[RING];
+  const int asoff[2] = {wino_vs_off(0, arow), wino_vs_off(1, arow)};
+  const int bsoff[2] = {A_STAGE + wino_v_off(0, brow, hi), A_STAGE + wino_v_off(1, brow, hi)};
+  auto load = [&](const float* L, int xi, a_t& a, float2& b) {
+    if constexpr (SPLIT) {
+      a = *reinterpret_cast<const f32x4*>(L + asoff[xi & 1] + (xi >> 1) * (WT * 8));
+      b = *reinterpret_cast<const float2*>(L + bsoff[xi & 1] + (xi >> 1) * (WC * 8));
+    } else {
+      if (X == 6) { a = make_float2(1.f, (float)lane); b = make_float2(2.f, (float)xi); return; }
+      a = *reinterpret_cast<const float2*>(L + aoff[xi & 1] + (xi >> 1) * (WT * 8));
+      b = *reinterpret_cast<const float2*>(L + boff[xi & 1] + (xi >> 1) * (WC * 8));
+    }
   };
 
   // 400 accumulators: hipcc gives EVERY MFMA of a kernel the same accumulator register class, so beyond 256 it
@@ -300,8 +346,14 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   // Wait states (cdna_hip_programming.md 5.7): an accumulate chain needs none; the leading s_nop 1 covers a
   // compiler v_mov into an A/B operand; the D -> VALU distance is padded once, after the K loop.
   auto in_agpr = [](int k) { return k % 5 < 3; };
-  auto mma = [&](int k, const float2& a, const float2& b) {
-    if (in_agpr(k)) {
+  auto mma = [&](int k, const a_t& a, const float2& b) {
+    if constexpr (SPLIT) {
+      const h8 ah = __builtin_bit_cast(h8, a);
+      const f32x4 bb = {b.x, b.y, b.x, b.y};                   // [block | block]: hi for lanes 0-31, lo for 32-63
+      const h8 bh = __builtin_bit_cast(h8, bb);
+      if (in_agpr(k)) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[k], 0, 0, 0);
+      else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(ah), "v"(bh));
+    } else if (in_agpr(k)) {
       acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[k], 0, 0, 0);
       acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
     } else {
@@ -527,8 +579,19 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       for (int xi = 0; xi < 26; ++xi) {
         const f32x2 z2 = {0.f, 0.f};
         const f32x2 p0 = xi < 25 ? vv[xi < 25 ? xi : 0][0] : z2, p1 = xi < 25 ? vv[xi < 25 ? xi : 0][1] : z2;
-        const f32x2 lo = swap ? p1 : p0, hi2 = swap ? p0 : p1;
-        const f32x4 v4 = {lo[0], lo[1], hi2[0], hi2[1]};
+        f32x4 v4;
+        if constexpr (SPLIT) {
+          _Float16 ah[4], al[4];
+          split_half(kSplitV * p0[0], ah[0], al[0]);
+          split_half(kSplitV * p0[1], ah[1], al[1]);
+          split_half(kSplitV * p1[0], ah[2], al[2]);
+          split_half(kSplitV * p1[1], ah[3], al[3]);
+          const h8 pk = {ah[0], ah[1], ah[2], ah[3], al[0], al[1], al[2], al[3]};
+          v4 = __builtin_bit_cast(f32x4, pk);
+        } else {
+          const f32x2 lo = swap ? p1 : p0, hi2 = swap ? p0 : p1;
+          v4 = (f32x4){lo[0], lo[1], hi2[0], hi2[1]};
+        }
         f32x4* gp = reinterpret_cast<f32x4*>(g + (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4));
         if (X == 3) {
           if (v4[0] + v4[3] == 123.456f) *gp = v4;
@@ -568,6 +631,35 @@ void wino_pack_weights(const ConvHost& c, float* out) {
     }
 }
 
+// the same in the split form: u' = 2^10 u as (hi, lo) halves, rows laid out by wino_v_off (block h = 0: hi, 1: lo)
+void wino_pack_weights_split(const ConvHost& c, float* out) {
+  static const double G[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6, -1.0 / 6, 1.0 / 6},
+                                 {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
+  const int cin = c.cin, cout = c.cout;
+  std::memset(out, 0, sizeof(float) * wino_weight_floats());
+  _Float16* o16 = reinterpret_cast<_Float16*>(out);
+  for (int o = 0; o < cout; ++o)
+    for (int ci = 0; ci < cin; ++ci) {
+      double k[3][3];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) k[a][b] = c.w[(2 - a) + 3 * ((2 - b) + 3 * (ci + (size_t)cin * o))];
+      const int cb = o / WC, ol = o % WC, st = ci / WK, cl = ci % WK;
+      for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j) {
+          double u = 0.0;
+          for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) u += G[i][a] * k[a][b] * G[j][b];
+          const int xi = i * 5 + j;
+          _Float16 hi, lo;
+          split_half((float)(u * (double)kSplitU), hi, lo);
+          const size_t base = ((size_t)cb * WNS + st) * B_STAGE;       // floats
+          o16[2 * (base + wino_v_off(xi, ol, 0)) + cl] = hi;
+          o16[2 * (base + wino_v_off(xi, ol, 1)) + cl] = lo;
+        }
+    }
+}
+float wino_split_descale() { return 1.f / (kSplitV * kSplitU); }
+
 size_t wino_weight_floats() { return (size_t)(kC / WC) * WNS * B_STAGE; }
 static long wino_blocks(int bcap, int T) {
   const long rpb = wino_rows_per_block(T);
@@ -576,23 +668,24 @@ static long wino_blocks(int bcap, int T) {
 size_t wino_v_floats(int bcap, int T) { return (size_t)wino_blocks(bcap, T) * WNS * A_STAGE; }
 bool wino_fusable(int N) { return wino_whole_boards((N + 2) / 3); }
 
-void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s) {
+void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s) {
   const int T = (N + 2) / 3;
   const int blocks = (int)wino_blocks(bcap, T);
-  hipLaunchKernelGGL((k_wino_in<32, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+  if (split) hipLaunchKernelGGL((k_wino_in<32, true, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+  else hipLaunchKernelGGL((k_wino_in<32, true, false>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
 }
 
 // y == nullptr: the activations are not needed in HBM (only their transform is); vnext == nullptr: no next
 // Winograd layer (or a board size whose tile blocks do not hold whole boards: wino_fusable(N) is false)
 void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
-                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
+                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s) {
   const int T = (N + 2) / 3;
   const int blocks = (int)wino_blocks(bcap, T);
   const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm4
   const dim3 grid(8 * per_xcd), block(256);
 #ifdef AGZ_TIMING_EXPERIMENTS
   static const int xp = getenv("AGZ_WINO_X") ? atoi(getenv("AGZ_WINO_X")) : 0;
-  if (xp && y && vnext && res) {
+  if (xp && y && vnext && res && !split) {
     auto kern = xp == 1 ? k_wino_gemm4<3, 1> : xp == 2 ? k_wino_gemm4<3, 2> : xp == 3 ? k_wino_gemm4<3, 3>
               : xp == 4 ? k_wino_gemm4<3, 4> : xp == 5 ? k_wino_gemm4<3, 5> : xp == 6 ? k_wino_gemm4<3, 6>
               : xp == 11 ? k_wino_gemm4<1, 0> : xp == 12 ? k_wino_gemm4<2, 0> : k_wino_gemm4<3, 0>;
@@ -600,6 +693,15 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
     return;
   }
 #endif
+  if (split) {
+    if (y && vnext)
+      hipLaunchKernelGGL((k_wino_gemm4<3, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    else if (vnext)
+      hipLaunchKernelGGL((k_wino_gemm4<2, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    else
+      hipLaunchKernelGGL((k_wino_gemm4<1, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    return;
+  }
   if (y && vnext)
     hipLaunchKernelGGL((k_wino_gemm4<3>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
   else if (vnext)

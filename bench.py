@@ -133,8 +133,11 @@ def main():
     ap.add_argument("--stagger", type=int, default=60, help="random opening prefix (moves) so games are at mixed stages")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
-                    help="tower arithmetic: f32 (default, the BASELINE metric) or f16 = the fp16 MFMA path of BASELINE configs[4]")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32s"],
+                    help="tower arithmetic: f32 (default, the BASELINE metric), f16 = the fp16 MFMA path of BASELINE configs[4], "
+                         "f32s = the f32 network with Winograd operands split into two f16 halves (fp16 MFMA, f32-grade results)")
+    ap.add_argument("--no-alt-precision", action="store_true",
+                    help="skip the extra (untimed for `value`) leg that repeats the K steps with --precision f32s")
     ap.add_argument("--single-device-test", action="store_true",
                     help="testing only: every rank uses cuda:0 and gloo, to exercise the multi-rank code path on a 1-GPU box")
     args = ap.parse_args()
@@ -200,6 +203,31 @@ def main():
     eng.profile_conv(False)
     s1 = eng.stats()
 
+    # Extra leg, reported beside `value`, never as it: the same K steps with the Winograd operands carried as two f16
+    # halves (AGZ_PRECISION_F32S: f32 network, f32 accumulate, fp16 MFMA; agrees with the float64 oracle as closely
+    # as the exact-f32 path does, tests/test_gpu_nn32s.py).  N = 1 only, exact-f32 runs only.
+    alt = None
+    if world == 1 and args.precision == "f32" and not args.no_alt_precision:
+        try:
+            eng.set_precision("f32s")
+            eng.step(args.warmup)
+            eng.sync()
+            a0 = eng.stats()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            eng.step(args.steps)
+            eng.sync()
+            torch.cuda.synchronize()
+            tb_ = time.perf_counter()
+            a1 = eng.stats()
+            alt = {"precision": "f32s: f32 network, Winograd GEMM operands as two f16 halves on v_mfma_f32_32x32x16_f16, f32 accumulate",
+                   "value": (a1["positions"] - a0["positions"]) / (tb_ - ta), "unit": "positions/s",
+                   "ms_per_step": 1e3 * (tb_ - ta) / args.steps, "steps": args.steps,
+                   "parity": "max |d pi|, |d v| vs the float64 oracle <= 1e-6 on the configs of tests/test_gpu_nn32s.py (bar 1e-4)"}
+            eng.set_precision("f32")
+        except Exception as ex:
+            alt = {"error": str(ex)}
+
     elapsed = t1 - t0
     d = {k: s1[k] - s0[k] for k in ("positions", "evals", "duplicate_evals", "terminal_visits", "root_visits",
                                     "games_finished", "steps")}
@@ -260,7 +288,7 @@ def main():
         value = d["positions"] / elapsed
         fpos = R * f_eval(N, tower)
         T = (N + 2) // 3
-        f16 = args.precision == "f16"
+        f16, f32s = args.precision == "f16", args.precision == "f32s"
         wino_ratio = 1.0 if f16 else 25.0 * T * T / (9.0 * N * N)   # executed / algorithmic multiplies of F(3x3,3x3)
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = (None, None) if (f16 or N != 9) else pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256))
@@ -272,7 +300,20 @@ def main():
         conv_s = conv_ms * 1e-3
         alg_tf = conv_flop / conv_s / 1e12 if conv_ms > 0 else None
         exe_tf = alg_tf * wino_ratio if alg_tf is not None else None
-        roofline = {
+        if f32s:
+            # split-operand form: the matrix pipe is 4x faster than the f32 MFMA it replaces and stops being the bound;
+            # the layer is bound by moving V (the 25 transformed planes) through HBM: measured traffic / launch time
+            # against the 8 TB/s HBM peak.  `achieved_algorithmic` stays the direct convolution's flops / time.
+            tb = traffic / (conv_ms * 1e-3 / max(conv_n, 1)) / 1e9 if traffic else None
+            roofline = {
+                "bound": "hbm", "kernel": "3x3 256->256 tower conv (Winograd F(3x3,3x3), operands as two f16 halves on "
+                                          "v_mfma_f32_32x32x16_f16, f32 accumulate)",
+                "achieved": tb, "peak": 8000.0, "unit": "GB/s", "frac": tb / 8000.0 if tb else None,
+                "traffic": traffic, "traffic_source": traffic_src, "achieved_algorithmic": alg_tf,
+                "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
+                "note": "traffic = HBM bytes per layer from the PMC passes of the f32 form (same buffers, same bytes)",
+            }
+        roofline = roofline if f32s else {
             "bound": "mfma",
             "kernel": "3x3 256->256 tower conv = k_conv3x3_f16 (implicit GEMM, v_mfma_f32_32x32x16_f16)" if f16 else
                       "3x3 256->256 tower conv (Winograd F(3x3,3x3) on v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)",
@@ -290,10 +331,11 @@ def main():
             "algorithmic_flop_per_launch_avg": conv_flop / max(conv_n, 1),
         }
         out = {
-            "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)" + (" [fp16 tower]" if f16 else ""),
+            "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)" + (" [fp16 tower]" if f16 else "")
+                      + (" [f32 as split f16 operands]" if f32s else ""),
             "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if f16 else "f32 (Winograd operands as 2 x f16, f32 accumulate)" if f32s else "f32", "data": "synthetic",
             "config": {
                 "workload": f"GoEnv({N}), tower_height={tower}, {R} readouts, {args.games} concurrent games per GPU, "
                             f"8 leaves per game per step (batch <= {8 * args.games} positions)",
@@ -312,6 +354,8 @@ def main():
         }
         if exchange is not None:
             out["exchange"] = exchange
+        if alt is not None:
+            out["alt_precision"] = alt
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, tower, R, args.cpu_baseline_seconds)

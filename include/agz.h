@@ -139,6 +139,12 @@ agz_status agz_net_set_winograd(agz_engine* e, int32_t on);
  * f32.  Mixed-precision inference: outputs agree with the f32 network to ~1e-3, not 1e-4. */
 #define AGZ_PRECISION_F32 0
 #define AGZ_PRECISION_F16 1
+/* AGZ_PRECISION_F32S: the f32 network of AGZ_PRECISION_F32 -- f32 activations, weights, accumulation, BatchNorm,
+ * residuals -- with the OPERANDS of the Winograd GEMMs carried as two IEEE halves each (x ~ hi + lo, 22 mantissa
+ * bits instead of 24) so that the products run on the fp16 MFMA (v_mfma_f32_32x32x16_f16, all four cross products,
+ * exact in f32) at 4x the f32 MFMA rate.  Opt-in; NOT what bench.py measures by default.  Outputs agree with the
+ * float64 oracle to ~1e-6 (bar 1e-4, tests/test_gpu_nn32s.py). */
+#define AGZ_PRECISION_F32S 2
 agz_status agz_net_set_precision(agz_engine* e, int32_t precision);
 
 /* HIP-event timing of every 3x3 256->256 tower-conv launch issued by subsequent steps /

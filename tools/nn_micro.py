@@ -17,7 +17,7 @@ ap.add_argument("--tower", type=int, default=10)
 ap.add_argument("--batches", type=int, nargs="+", default=[1024, 4096, 8192])
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--algos", type=int, nargs="+", default=[1, 0], help="1 = winograd, 0 = direct")
-ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="f16 = fp16-operand tower (algos ignored)")
+ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32s"], help="f16 = fp16-operand tower (algos ignored)")
 args = ap.parse_args()
 
 N, t = args.board, args.tower
