@@ -17,7 +17,7 @@ dur = collections.defaultdict(list)
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(", ", ";")       # keep the CSV one-field-per-comma
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 cols = ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]

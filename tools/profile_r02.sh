@@ -10,7 +10,7 @@ O=gpurun_out/r02prof_$P
 mkdir -p $O
 export TMPDIR=/tmp
 EXTRA=""
-[ "$P" = f16 ] && EXTRA="--precision f16"
+[ "$P" != f32 ] && EXTRA="--precision $P"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline $EXTRA > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 find $O/stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 for C in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
