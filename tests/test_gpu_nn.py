@@ -69,6 +69,33 @@ def test_forward_matches_oracle(N, tower, B, winograd):
     eng.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("N", [3, 4, 6, 8, 10, 12, 13, 16])
+def test_every_tiling_class_of_the_winograd_tower(N, precision):
+    """Tile blocks hold whole boards for N <= 12 (T*T = 1, 4, 9, 16 tiles per board: 64, 64, 63, 64 rows used,
+    next layer's input transform fused into the GEMM epilogue) and are packed densely above (N = 13..15: 25
+    tiles, 16..18: 36, 19: 49; separate input transform); boards whose side is not a multiple of 3 have tiles
+    hanging over the edge.  One parity check per class, batch sizes that leave a partial last block."""
+    tower, B = 2, 23
+    A = N * N + 1
+    rng = np.random.RandomState(N)
+    onet = L.or_net_new(N, tower)
+    L.or_net_init_synthetic(onet, 3)
+    randomize_bn(onet, list(range(0, 1 + 2 * tower)) + [orc.L_VALUE_CONV, orc.L_POLICY_CONV], rng)
+    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    copy_weights_from_oracle(eng, onet, tower)
+    eng.set_precision(precision)
+    feats = (rng.rand(B, 17 * N * N) < 0.3).astype(np.float32)
+    feats[:, 16 * N * N:] = np.where(rng.rand(B, 1) < 0.5, 1.0, -1.0)
+    pi64, v64 = oracle_forward64(onet, feats, A)
+    gpi, gv = eng.forward_features(feats)
+    assert np.abs(gpi - pi64).max() <= TOL and np.abs(gv - v64).max() <= TOL, (np.abs(gpi - pi64).max(), np.abs(gv - v64).max())
+    spi, sv = eng.forward_features(feats[5:6])
+    assert (spi[0] == gpi[5]).all() and sv[0] == gv[5]
+    L.or_net_free(onet)
+    eng.close()
+
+
 def test_synthetic_init_matches_oracle_stream():
     """agz_net_init_synthetic and the oracle draw the same tensors from the shared draw stream"""
     N, tower = 9, 1
