@@ -97,7 +97,12 @@ __device__ __forceinline__ void glds16h(const void* g, unsigned lds_byte_addr) {
 
 // CH = output channels per workgroup: 256 (8 waves, one workgroup per CU) or 128 (4 waves, TWO workgroups
 // per CU: one's barriers, prologue and epilogue hide behind the other's MFMAs).
-// DBG: timing experiments only: 0 = product; 1 = no MFMA; 2 = no DMA in the loop; 3 = no LDS reads; 4 = no main loop; 5 = no epilogue
+// DBG: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (wrong results): 0 = product; 1 = no MFMA;
+// 2 = no DMA in the loop; 3 = no LDS reads; 4 = no main loop; 5 = no epilogue.  What they showed (round 2): the
+// 0.68 ms main loop is the SUM of its three phases (MFMA 0.21 + DMA issue 0.27 + LDS reads 0.23 ms as additive shares),
+// i.e. the waves of a SIMD do not overlap them; reading a stage's operands one stage ahead (second register set, a
+// fourth weight image, three stages in flight) and scalar-base DMA addressing were each built, bit-identical, and did
+// not move it (0.79 / 0.81 ms against 0.77): what serialises is the per-stage barrier of a 512-cycle stage.
 template <int DBG, int CH>
 __global__ __launch_bounds__(CH / 32 * 64, CH == 128 ? 2 : 1) void k_conv3x3_f16_dma(const _Float16* __restrict__ x, const uint16_t* __restrict__ wi,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
@@ -337,12 +342,15 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
                        int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
   const long rows = (long)bcap * N * N;
   const int tiles = (int)((rows + HM - 1) / HM);
-  static const int dbg = getenv("AGZ_C16_DEBUG") ? atoi(getenv("AGZ_C16_DEBUG")) : 0;   // timing experiments only
-  static const int ch = getenv("AGZ_C16_CH") ? atoi(getenv("AGZ_C16_CH")) : 128;
   const _Float16* xh = (const _Float16*)x;
 #define AGZ_C16_LAUNCH(D, C)                                                                                       \
   hipLaunchKernelGGL((k_conv3x3_f16_dma<D, C>), dim3(tiles * (kC / C)), dim3(C / 32 * 64), 0, s, xh, wi, scale, shift, \
                      res, res_f32, y, out_f32, d_count, N, relu)
+#ifdef AGZ_TIMING_EXPERIMENTS
+  // timing experiments only (make EXTRA=-DAGZ_TIMING_EXPERIMENTS): kernel variants with a phase compiled out
+  // (wrong results) and the one-workgroup-per-CU form, selected by environment; tools/c16_x.sh
+  static const int dbg = getenv("AGZ_C16_DEBUG") ? atoi(getenv("AGZ_C16_DEBUG")) : 0;
+  static const int ch = getenv("AGZ_C16_CH") ? atoi(getenv("AGZ_C16_CH")) : 128;
   if (ch == 256) {
     switch (dbg) {
       case 1: AGZ_C16_LAUNCH(1, 256); break;
@@ -352,16 +360,18 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
       case 5: AGZ_C16_LAUNCH(5, 256); break;
       default: AGZ_C16_LAUNCH(0, 256);
     }
-  } else {
-    switch (dbg) {
-      case 1: AGZ_C16_LAUNCH(1, 128); break;
-      case 2: AGZ_C16_LAUNCH(2, 128); break;
-      case 3: AGZ_C16_LAUNCH(3, 128); break;
-      case 4: AGZ_C16_LAUNCH(4, 128); break;
-      case 5: AGZ_C16_LAUNCH(5, 128); break;
-      default: AGZ_C16_LAUNCH(0, 128);
-    }
+    return;
   }
+  switch (dbg) {
+    case 1: AGZ_C16_LAUNCH(1, 128); return;
+    case 2: AGZ_C16_LAUNCH(2, 128); return;
+    case 3: AGZ_C16_LAUNCH(3, 128); return;
+    case 4: AGZ_C16_LAUNCH(4, 128); return;
+    case 5: AGZ_C16_LAUNCH(5, 128); return;
+    default: break;
+  }
+#endif
+  AGZ_C16_LAUNCH(0, 128);
 #undef AGZ_C16_LAUNCH
 }
 
