@@ -8,6 +8,7 @@
 #include <string>
 
 #include "../../include/agz.h"
+#include "../../include/agz_debug.h"
 
 namespace agz {
 

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const bool swap = (row >> 4) & 1;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll 1
-    for (int sl = wave; sl < WC / WK; sl += 4) {
+    for (int sl = wave; sl < WC / WK; sl += 4) {      // (unrolling by 2 for ILP: no change)
       f32x4 d[25];
 #pragma unroll
       for (int q = 0; q < 25; ++q) {

@@ -360,16 +360,8 @@ agz_status agz_tree_node_board(agz_engine* e, int32_t g, int32_t node, int8_t* o
 agz_status agz_tree_pending_vlosses(agz_engine* e, int32_t g, int32_t* out);
 agz_status agz_tree_set_draw(agz_engine* e, int32_t g, uint64_t game_id, uint32_t sel);
 
-/* ---------------------------------------------------------------- diagnostics ----------- */
-/* Evaluate the draw stream (include/agz_draws.h) ON THE DEVICE so tests can check that gfx950
- * and the host produce bit-identical draws: gamma_out[a] = a-th un-normalised Dirichlet
- * component for (seed, game, move). */
-agz_status agz_debug_draws(agz_engine* e, uint64_t seed, uint64_t game, uint32_t move, int32_t n,
-                           double alpha, double* gamma_out);
-/* op 0: agz_log(x) 1: agz_exp(x) 2: agz_pow(x, 0.98) 3: (double)sqrtf((float)x)
- * 4: (double)((float)x / (float)y) 5: PUCT score of (W=x, N=y, P=0.25, to_play=-1, N_node=y+7) */
-agz_status agz_debug_math(agz_engine* e, int32_t op, const double* x, const double* y, int32_t n,
-                          double* out);
+/* Test hooks (device-side evaluation of the draw stream, single-tree introspection setters) are declared in
+ * include/agz_debug.h: exported by the library for the parity tests, not part of the drop-in surface. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,28 @@
+/* agz_debug.h -- test hooks of libagz.so.  NOT part of the drop-in boundary (include/agz.h): nothing a host of
+ * the reference would call.  The parity tests use them to check that gfx950 and the CPU oracle evaluate the shared
+ * draw stream (include/agz_draws.h) and the mixed Float32/Float64 PUCT arithmetic bit for bit. */
+#ifndef AGZ_DEBUG_H
+#define AGZ_DEBUG_H
+
+#include "agz.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- diagnostics ----------- */
+/* Evaluate the draw stream (include/agz_draws.h) ON THE DEVICE so tests can check that gfx950
+ * and the host produce bit-identical draws: gamma_out[a] = a-th un-normalised Dirichlet
+ * component for (seed, game, move). */
+agz_status agz_debug_draws(agz_engine* e, uint64_t seed, uint64_t game, uint32_t move, int32_t n,
+                           double alpha, double* gamma_out);
+/* op 0: agz_log(x) 1: agz_exp(x) 2: agz_pow(x, 0.98) 3: (double)sqrtf((float)x)
+ * 4: (double)((float)x / (float)y) 5: PUCT score of (W=x, N=y, P=0.25, to_play=-1, N_node=y+7) */
+agz_status agz_debug_math(agz_engine* e, int32_t op, const double* x, const double* y, int32_t n,
+                          double* out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_functions():
-    hdr = open(os.path.join(ROOT, "include", "agz.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "agz.h")).read() + open(os.path.join(ROOT, "include", "agz_debug.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"^\s*(?:agz_status|int32_t|int64_t|void|const char\*)\s+(agz_[a-z_0-9]+)\s*\(", hdr, flags=re.M)))
 
