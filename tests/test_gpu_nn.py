@@ -122,7 +122,7 @@ def test_weight_shape_errors():
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16"])
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32s"])
 def test_full_batch_is_deterministic_and_matches_small_batches(precision):
     """race screen at the bench's batch size (8192 positions, every CU busy, DMA rings full): repeated
     forwards are bit-identical, and so is a slice evaluated as a small batch"""

@@ -7,7 +7,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, alphago_jl_amd as ag, orc
 N=9; G=1024; TOTAL=3000
 eng = ag.Engine(board_size=N, tower_height=2, games=G, num_readouts=32, seed=21, record_capacity_games=TOTAL+64)
-eng.init_synthetic(0); eng.start(TOTAL)
+eng.init_synthetic(0); eng.set_precision(sys.argv[1] if len(sys.argv) > 1 else "f32"); eng.start(TOTAL)
 t=time.time(); steps=0
 while eng.records_count() < TOTAL and steps < 20000:
     eng.step(50); steps += 50
