@@ -3,6 +3,7 @@
 // /root/reference/src/resnet.jl:11-32.  See DESIGN.md "Network kernels".
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -64,6 +65,18 @@ class Net {
   DenseHost* dense(int layer);
   const DenseHost* dense(int layer) const;
   void mark_dirty() { dirty_ = true; packed16_ = false; }
+  // The trainer keeps the master copy of the parameters on the device between steps; the host copies (and with them
+  // every inference pack) are refreshed lazily: whoever is about to read or write a host parameter calls sync_host()
+  // first.  param_version() moves whenever the host copies are written from outside (set, init_synthetic).
+  void set_host_sync(std::function<void()> f) { host_sync_ = std::move(f); }
+  void set_host_stale(bool stale) { host_stale_ = stale; }
+  void sync_host() const {
+    if (host_stale_ && host_sync_) {
+      host_stale_ = false;          // (first: the callback itself reads and writes host parameters)
+      host_sync_();
+    }
+  }
+  uint64_t param_version() const { return param_version_; }
 
   double flops_per_eval() const;         // BASELINE.md F_eval
   double conv_flops_per_launch(int B) const { return 2.0 * B * P_ * 9.0 * kC * kC; }
@@ -77,6 +90,9 @@ class Net {
   std::vector<ConvHost> tconv_;
   DenseHost vfc1_, vfc2_, pfc_;
   bool dirty_ = true;
+  std::function<void()> host_sync_;
+  mutable bool host_stale_ = false;
+  uint64_t param_version_ = 0;
 
   // device-resident packed parameters
   DevBuf<float> d_wstem_, d_wtower_;      // [cout][9*cin_pad] per layer
@@ -117,7 +133,8 @@ class Trainer {
  private:
   struct Param;
   void upload();
-  void download(const std::vector<std::vector<float>>& bn_mean, const std::vector<std::vector<float>>& bn_var, long M);
+  void download();            // device master copies -> host parameters (Net::sync_host)
+  uint64_t uploaded_version_ = ~0ull;
   Net& net_;
   hipStream_t stream_;
   std::vector<std::unique_ptr<Param>> params_;

@@ -391,6 +391,8 @@ void Net::set(int layer, int kind, const float* data, int64_t count) {
   AGZ_REQUIRE(want >= 0, AGZ_BAD_ARGUMENT, "agz_net_set_weights: no parameter (layer %d, kind %d)", layer, kind);
   AGZ_REQUIRE(want == count, AGZ_BAD_SHAPE, "agz_net_set_weights: layer %d kind %d expects %lld floats, got %lld",
               layer, kind, (long long)want, (long long)count);
+  sync_host();
+  ++param_version_;
   if (ConvHost* c = conv(layer)) {
     if (kind == AGZ_K_BN_EPS) c->eps = data[0];
     else std::memcpy(conv_field(c, kind)->data(), data, sizeof(float) * (size_t)count);
@@ -407,6 +409,7 @@ void Net::get(int layer, int kind, float* out, int64_t count) const {
   AGZ_REQUIRE(want >= 0, AGZ_BAD_ARGUMENT, "agz_net_get_weights: no parameter (layer %d, kind %d)", layer, kind);
   AGZ_REQUIRE(want == count, AGZ_BAD_SHAPE, "agz_net_get_weights: layer %d kind %d holds %lld floats, asked %lld",
               layer, kind, (long long)want, (long long)count);
+  sync_host();
   if (const ConvHost* c = conv(layer)) {
     if (kind == AGZ_K_BN_EPS) out[0] = c->eps;
     else std::memcpy(out, conv_field(const_cast<ConvHost*>(c), kind)->data(), sizeof(float) * (size_t)count);
@@ -429,6 +432,8 @@ static void glorot(std::vector<float>& w, double fan_in, double fan_out, uint64_
 }
 
 void Net::init_synthetic(uint64_t seed) {
+  host_stale_ = false;          // everything is about to be overwritten
+  ++param_version_;
   for (int l = 0; l <= 2 * tower_; ++l) {
     ConvHost* c = conv(l);
     const int cin = c->cin, cout = c->cout, k = c->k;
@@ -472,6 +477,7 @@ static void bn_affine(const ConvHost& c, float* scale, float* shift) {
 }
 
 void Net::pack() {
+  sync_host();
   if (precision_ == 2 && tower_ > 0 && (dirty_ || !packed_split_)) {
     const size_t uper = wino_weight_floats();
     std::vector<float> u(uper * 2 * tower_);

@@ -348,14 +348,25 @@ struct Trainer::Param {
   size_t n = 0;
 };
 
-Trainer::Trainer(Net& net, hipStream_t s) : net_(net), stream_(s) {}
-Trainer::~Trainer() {}
+Trainer::Trainer(Net& net, hipStream_t s) : net_(net), stream_(s) {
+  net_.set_host_sync([this] { download(); });
+}
+Trainer::~Trainer() { net_.set_host_sync(nullptr); }
 
 void Trainer::reset() { have_vel_ = false; }
 
 // host parameters (Flux layouts) -> training layouts on the device.  Convolutions: Wt[cout][tap][cin_pad], the layout
 // of the forward kernel (true-convolution flip applied); everything else as it is.
 void Trainer::upload() {
+  // the device copies are current unless somebody wrote the host parameters since the last step
+  if (!params_.empty() && uploaded_version_ == net_.param_version()) {
+    if (!have_vel_)
+      for (auto& p : params_) AGZ_HIP(hipMemsetAsync(p->vel.p, 0, sizeof(float) * p->n, stream_));
+    have_vel_ = true;
+    return;
+  }
+  net_.sync_host();
+  uploaded_version_ = net_.param_version();
   const int t = net_.tower(), L = 1 + 2 * t;
   if (params_.empty())
     for (size_t i = 0; i < (size_t)4 * L + 8 + 6; ++i) params_.emplace_back(new Param);
@@ -400,18 +411,12 @@ void Trainer::upload() {
 }
 
 // the inverse of upload(), plus the running BatchNorm statistics; marks the inference packs dirty
-void Trainer::download(const std::vector<std::vector<float>>& bn_mean, const std::vector<std::vector<float>>& bn_var, long M) {
+void Trainer::download() {
   const int t = net_.tower(), L = 1 + 2 * t;
   auto get = [&](Param& p, std::vector<float>& h) {
     h.resize(p.n);
     AGZ_HIP(hipMemcpyAsync(h.data(), p.theta.p, sizeof(float) * p.n, hipMemcpyDeviceToHost, stream_));
     AGZ_HIP(hipStreamSynchronize(stream_));
-  };
-  auto running = [&](ConvHost& c, const std::vector<float>& mean, const std::vector<float>& var) {
-    for (int o = 0; o < c.cout; ++o) {
-      c.mean[o] = (1.f - kBnMomentum) * c.mean[o] + kBnMomentum * mean[o];
-      c.var[o] = (1.f - kBnMomentum) * c.var[o] + kBnMomentum * var[o] * (float)((double)M / (double)(M - 1));
-    }
   };
   for (int l = 0; l < L; ++l) {
     ConvHost& c = *net_.conv(l);
@@ -426,18 +431,14 @@ void Trainer::download(const std::vector<std::vector<float>>& bn_mean, const std
     get(*params_[4 * l + 1], c.b);
     get(*params_[4 * l + 2], c.gamma);
     get(*params_[4 * l + 3], c.beta);
-    running(c, bn_mean[l], bn_var[l]);
   }
   size_t k = (size_t)4 * L;
-  int hl = L;
   for (int l : {AGZ_L_VALUE_CONV, AGZ_L_POLICY_CONV}) {
     ConvHost& c = *net_.conv(l);
     get(*params_[k++], c.w);
     get(*params_[k++], c.b);
     get(*params_[k++], c.gamma);
     get(*params_[k++], c.beta);
-    running(c, bn_mean[hl], bn_var[hl]);
-    ++hl;
   }
   for (int l : {AGZ_L_VALUE_FC1, AGZ_L_VALUE_FC2, AGZ_L_POLICY_FC}) {
     DenseHost& d = *net_.dense(l);
@@ -652,7 +653,20 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
   bv[L] = {hst[ho + 1]};
   bm[L + 1] = {hst[ho + 3], hst[ho + 4]};
   bv[L + 1] = {hst[ho + 5], hst[ho + 6]};
-  download(bm, bv, M);
+  // running statistics (Flux: (1 - 0.1) old + 0.1 batch, variance with the m / (m - 1) correction) live on the host:
+  // the trainer itself never reads them
+  auto running = [&](ConvHost& c, const std::vector<float>& mean, const std::vector<float>& var) {
+    for (int o = 0; o < c.cout; ++o) {
+      c.mean[o] = (1.f - kBnMomentum) * c.mean[o] + kBnMomentum * mean[o];
+      c.var[o] = (1.f - kBnMomentum) * c.var[o] + kBnMomentum * var[o] * (float)((double)M / (double)(M - 1));
+    }
+  };
+  for (int l = 0; l < L; ++l) running(*net_.conv(l), bm[l], bv[l]);
+  running(*net_.conv(AGZ_L_VALUE_CONV), bm[L], bv[L]);
+  running(*net_.conv(AGZ_L_POLICY_CONV), bm[L + 1], bv[L + 1]);
+  // the trained parameters stay on the device; host copies and inference packs catch up when somebody needs them
+  net_.set_host_stale(true);
+  net_.mark_dirty();
 }
 
 }  // namespace agz
