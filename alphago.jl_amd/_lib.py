@@ -144,6 +144,7 @@ def load():
         "agz_records_features": (i32, [E, i64, f32p]),
         "agz_replay_features": (i32, [E, i16p, i64, i32p, i32p, i32, C.c_void_p, i32]),
         "agz_replay_ingest_packed": (i32, [E, C.c_void_p, i64, i32, P(i64)]),
+        "agz_replay_ingest_gathered": (i32, [E, C.c_void_p, i32, i32, i64, P(i64), P(i64)]),
         "agz_replay_count": (i64, [E]),
         "agz_replay_positions": (i64, [E]),
         "agz_replay_header": (i32, [E, i64, P(GameHeader)]),

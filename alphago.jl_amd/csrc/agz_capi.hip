@@ -227,6 +227,22 @@ agz_status agz_replay_ingest_packed(agz_engine* e, const void* packed, int64_t n
     if (added_out) *added_out = n;
   });
 }
+agz_status agz_replay_ingest_gathered(agz_engine* e, const void* buf, int32_t is_device, int32_t world,
+                                      int64_t chunk_stride, const int64_t* counts, int64_t* added_out) {
+  return guard(e, [&](agz::Engine& E) {
+    AGZ_REQUIRE(buf && counts && world >= 1 && chunk_stride >= 0 && chunk_stride % 8 == 0, AGZ_BAD_ARGUMENT, "bad gather buffer");
+    std::vector<int64_t> coff((size_t)world), cbytes((size_t)world), cnrec((size_t)world);
+    for (int r = 0; r < world; ++r) {
+      AGZ_REQUIRE(counts[2 * r] >= 0 && counts[2 * r + 1] >= 0 && counts[2 * r + 1] <= chunk_stride && counts[2 * r + 1] % 8 == 0,
+                  AGZ_BAD_ARGUMENT, "chunk %d: %lld records in %lld bytes", r, (long long)counts[2 * r], (long long)counts[2 * r + 1]);
+      coff[r] = (int64_t)r * chunk_stride;
+      cnrec[r] = counts[2 * r];
+      cbytes[r] = counts[2 * r + 1];
+    }
+    const int64_t n = E.replay_ingest_gathered(buf, is_device != 0, (size_t)world * (size_t)chunk_stride, coff, cbytes, cnrec);
+    if (added_out) *added_out = n;
+  });
+}
 int64_t agz_replay_count(agz_engine* e) { return (e && e->impl) ? e->impl->replay_count() : -1; }
 int64_t agz_replay_positions(agz_engine* e) { return (e && e->impl) ? e->impl->replay_positions() : -1; }
 agz_status agz_replay_header(agz_engine* e, int64_t k, agz_game_header* out) {

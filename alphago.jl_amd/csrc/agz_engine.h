@@ -47,6 +47,8 @@ class Engine {
   // device replay arena: finished games of every rank, packed, resident in HBM
   int64_t replay_ingest(const void* packed, int64_t nbytes, bool is_device);
   int64_t replay_ingest_local();
+  int64_t replay_ingest_gathered(const void* buf, bool is_device, size_t nbytes, const std::vector<int64_t>& coff,
+                                 const std::vector<int64_t>& cbytes, const std::vector<int64_t>& cnrec);
   int64_t replay_ingest_chunks(const uint8_t* dbuf, const std::vector<int64_t>& coff,
                                const std::vector<int64_t>& cbytes, const std::vector<int64_t>& cnrec);
   int64_t replay_count() const { return (int64_t)rp_hdr_.size(); }

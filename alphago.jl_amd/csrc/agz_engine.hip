@@ -711,6 +711,17 @@ int64_t Engine::replay_ingest(const void* packed, int64_t nbytes, bool is_device
   return replay_ingest_chunks(d, {0}, {nbytes}, {-1});
 }
 
+int64_t Engine::replay_ingest_gathered(const void* buf, bool is_device, size_t nbytes, const std::vector<int64_t>& coff,
+                                       const std::vector<int64_t>& cbytes, const std::vector<int64_t>& cnrec) {
+  const uint8_t* d = (const uint8_t*)buf;
+  if (!is_device) {
+    s_pack_.ensure(std::max<size_t>(nbytes, 8));
+    AGZ_HIP(hipMemcpyAsync(s_pack_.p, buf, nbytes, hipMemcpyHostToDevice, stream_));
+    d = s_pack_.p;
+  }
+  return replay_ingest_chunks(d, coff, cbytes, cnrec);
+}
+
 int64_t Engine::replay_ingest_local() {
   const int64_t need = records_packed_size();
   if (need == 0) return 0;

@@ -247,6 +247,12 @@ agz_status agz_replay_features(agz_engine* e, const int16_t* moves, int64_t nmov
  * device buffer, e.g. games loaded from disk or received by other means; added_out may be NULL */
 agz_status agz_replay_ingest_packed(agz_engine* e, const void* packed, int64_t nbytes, int32_t is_device,
                                     int64_t* added_out);
+/* the same for the receive buffer of a padded all-gather the HOST performed with its own communication library
+ * (MPI.jl, Distributed): `world` chunks of `chunk_stride` bytes, chunk r holding counts[2r] records in its first
+ * counts[2r+1] bytes (what agz_records_count / agz_records_packed_size said on rank r).  This is also the second
+ * half of agz_allgather_records (which does the gather itself over RCCL). */
+agz_status agz_replay_ingest_gathered(agz_engine* e, const void* buf, int32_t is_device, int32_t world,
+                                      int64_t chunk_stride, const int64_t* counts, int64_t* added_out);
 int64_t agz_replay_count(agz_engine* e);                 /* games in the arena                       */
 int64_t agz_replay_positions(agz_engine* e);             /* sum of num_moves = length(pos_buffer)    */
 agz_status agz_replay_header(agz_engine* e, int64_t k, agz_game_header* out);

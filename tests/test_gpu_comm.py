@@ -99,6 +99,31 @@ def test_allgather_records_through_the_c_abi_over_rccl():
     e1.close()
 
 
+def test_ingest_of_a_padded_multi_rank_gather_buffer():
+    """the second half of agz_allgather_records for a world of three ranks (one of them with nothing to send): the
+    receive buffer of the padded all-gather is laid out by hand from three engines' packed exports"""
+    engs = [play(r, 3, n) for r, n in ((0, 4), (1, 3))]
+    packs = [e.records_packed() for e in engs] + [np.zeros(0, np.uint8)]
+    counts = [(e.records_count(), p.size) for e, p in zip(engs, packs)] + [(0, 0)]
+    stride = (max(p.size for p in packs) + 255) // 256 * 256
+    buf = np.full(3 * stride, 0xAB, np.uint8)                    # the padding is garbage and must never be read
+    for r, p in enumerate(packs):
+        buf[r * stride: r * stride + p.size] = p
+    dst = engs[0]
+    assert dst.replay_ingest_gathered(buf, 3, stride, counts) == 7 and dst.replay_count() == 7
+    want = {int(r["game_id"]): r for e in engs for r in e.records()}
+    got = [dst.replay_record(k) for k in range(7)]
+    assert [int(r["game_id"]) % 3 for r in got] == [0, 0, 0, 0, 1, 1, 1]          # rank order
+    assert all(same_record(r, want[int(r["game_id"])]) for r in got)
+    bad = list(counts)
+    bad[1] = (counts[1][0] + 1, counts[1][1])                    # a rank that announces one record too many
+    with pytest.raises(ag.AgzError):
+        dst.replay_ingest_gathered(buf, 3, stride, bad)
+    assert dst.replay_count() == 7
+    for e in engs:
+        e.close()
+
+
 def test_broadcast_weights_through_the_c_abi_over_rccl():
     eng = ag.Engine(board_size=5, tower_height=1, games=1, num_readouts=8, max_nodes_per_game=16)
     eng.init_synthetic(4)
