@@ -249,11 +249,14 @@ __device__ __forceinline__ void glds16s(const float* gbase_uniform, unsigned lan
 // K loop: operands are read 4 planes (>= 256 MFMA cycles) ahead through a ring of 5 register pairs; the stage
 // barrier sits in the READ stream (before the first read of the next stage, i.e. 4 planes before the stage's
 // last MFMA), so the MFMAs of planes 21..24 cover the barrier and the first LDS latencies of the next stage.
-// The epilogue's tile image: img[X][16 units of 16 B], X = tile row * 9 + output k, this workgroup's 64 channels
-// of output point X.  Unit u holds channel group u ^ (X & 15): rows are exactly 256 B (an LDS-DMA instruction
-// fills four of them, each lane choosing the global 16 B that belongs in its slot), a wave whose lanes are
-// tile rows reads one channel group of 16 different X per LDS cycle from 16 different units, and a wave whose
-// lanes are channels touches every bank once.
+// The epilogue's tile image: img[X][16 units of 16 B], X = output k * 64 + tile row, this workgroup's 64 channels
+// of output point X.  Unit u holds channel group u ^ (X & 15) = u ^ (row & 15): rows are exactly 256 B (an LDS-DMA
+// instruction fills four of them, each lane choosing the global 16 B that belongs in its slot), a wave whose lanes are
+// tile rows reads one channel group of 16 different rows per LDS cycle from 16 different units, and a wave whose
+// lanes are channels touches every bank once.  k-major, so that the swizzle of a lane does not depend on k: the nine
+// outputs of a (row, channel) pair sit at nine constant offsets from one address, and a thread of the flat pass keeps
+// one channel group for all its elements -- the epilogue is VALU-issue bound (a lone wave per SIMD), address
+// arithmetic per access is what it can least afford.
 constexpr int IMG_FLOATS = WT * 9 * WC;          // 147,456 B
 
 // MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   };
 
   for (int idx = tid; idx < WT * 9; idx += 256) {     // (published by the barrier in front of the first operand reads)
-    const int row = idx / 9, k = idx % 9;
+    const int row = idx & (WT - 1), k = idx >> 6;       // X = k * 64 + row
     const long tile = (long)tb * RPB + row;
     int off = -1;
     if (row < RPB && tile < Mt) {
@@ -393,9 +396,12 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       }
       if (t < WXI) load(L, t, ra[t % RING], rb[t % RING]);
       else if (next) load(Ln, t - WXI, ra[t % RING], rb[t % RING]);
-      if (more && k >= 6 && k < 19) {     // one piece per plane slot in the middle of the stage (vs every other slot: -2 %)
+      // one piece per plane slot: in the middle of the stage in the f32 form (vs every other slot: -2 %), at its very
+      // top in the split form, whose matrix work is short and whose loop waits for the stream anyway
+      constexpr int D0 = SPLIT ? 0 : 6;
+      if (more && k >= D0 && k < D0 + 13) {
         __builtin_amdgcn_sched_barrier(0);
-        if (X != 4) dma(st + 2, dbuf, k - 6);
+        if (X != 4) dma(st + 2, dbuf, k - D0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (X != 5) mma(k, ra[k % RING], rb[k % RING]);
@@ -475,18 +481,24 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     // fraction of the ds_write rate (+0.75 ms per layer measured): read the nine residuals of a row, add, write
     auto rows = [&](auto with_res) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int Xr = (wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi) * 9;
-        float rr[9];
+      for (int e0 = 0; e0 < 16; e0 += 4) {          // four tile rows at a time: 36 LDS reads behind one wait
+        float* p0[4];
+        float rr[4][9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-          rr[k] = decltype(with_res)::value ? img[(Xr + k) * WC + 4 * ((col >> 2) ^ ((Xr + k) & 15)) + (col & 3)] : 0.f;
+        for (int ee = 0; ee < 4; ++ee) {
+          const int e = e0 + ee, row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          p0[ee] = img + row * WC + 4 * ((col >> 2) ^ (row & 15)) + (col & 3);     // output k at p0 + k * 64 * 64
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          float v = o[k][e] * sc + sh + rr[k];
-          if (relu_now) v = fmaxf(v, 0.f);
-          img[(Xr + k) * WC + 4 * ((col >> 2) ^ ((Xr + k) & 15)) + (col & 3)] = v;
+          for (int k = 0; k < 9; ++k) rr[ee][k] = decltype(with_res)::value ? p0[ee][k * (WT * WC)] : 0.f;
         }
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            float v = o[k][e0 + ee] * sc + sh + rr[ee][k];
+            if (relu_now) v = fmaxf(v, 0.f);
+            p0[ee][k * (WT * WC)] = v;
+          }
       }
     };
     if (res) rows(std::true_type{});
@@ -497,19 +509,28 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   if (pass1b) {
     // phase 1b: element = (row, k, 4 channels); 16 consecutive lanes cover the 256 contiguous bytes of one point
     constexpr int PER = WT * 9 * (WC / 4) / 256;      // 36 per thread
+    // element i of thread tid: point X = (tid >> 4) + 16 i, unit tid & 15 -> channel group (tid ^ (tid >> 4)) & 15 for
+    // every i: one LDS address and one channel offset per thread, the rest are immediate offsets
+    const int cg4 = 4 * ((tid ^ (tid >> 4)) & 15);
+    f32x4* ip0 = reinterpret_cast<f32x4*>(img) + tid;
+    const int* pt0 = ptab + (tid >> 4);
+    int offs[PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int idx = tid + 256 * i, Xp = idx >> 4;
-      const int off = ptab[Xp];
-      if (off < 0) continue;
-      f32x4* ip = reinterpret_cast<f32x4*>(img + idx * 4);       // unit idx & 15 of point Xp holds group (idx ^ Xp) & 15
-      f32x4 v = *ip;
-      if (relu) {
+    for (int i = 0; i < PER; ++i) offs[i] = pt0[16 * i];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+    for (int i0 = 0; i0 < PER; i0 += 12) {            // twelve elements at a time: no branch between a load and its use
+      f32x4 v[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) v[j] = ip0[256 * (i0 + j)];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        if (relu) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[j][c] = fmaxf(v[j][c], 0.f);
+        }
+        if ((MODE & 1) && offs[i0 + j] >= 0) *reinterpret_cast<f32x4*>(y + offs[i0 + j] + cg4) = v[j];
+        if (MODE & 2) ip0[256 * (i0 + j)] = v[j];      // (dead points: never read)
       }
-      if (MODE & 1) *reinterpret_cast<f32x4*>(y + off + 4 * ((idx ^ Xp) & 15)) = v;
-      if (MODE & 2) *ip = v;
     }
     if (MODE & 2) __syncthreads();
   }
@@ -532,8 +553,14 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
         const int pi = 3 * ti - 1 + u, pj = 3 * tj - 1 + v;
         const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
         // the point lives in tile (pi / 3, pj / 3) of the same board, output k = (pi % 3) * 3 + pj % 3
-        poff[u * 5 + v] = ok ? (lb * TT + (pi / 3) * T + pj / 3) * 9 + (pi % 3) * 3 + pj % 3 : -1;      // = X
+        poff[u * 5 + v] = ok ? ((pi % 3) * 3 + pj % 3) * WT + lb * TT + (pi / 3) * T + pj / 3 : -1;      // = X
       }
+    int pbase[25], pxm[25];            // float offset of point X's row in img, and its swizzle X & 15
+#pragma unroll
+    for (int q = 0; q < 25; ++q) {
+      pbase[q] = poff[q] * WC;
+      pxm[q] = poff[q] & 15;
+    }
     // a V image row is one plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1 (wino_v_off)
     const bool swap = (row >> 4) & 1;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -543,16 +570,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 #pragma unroll
       for (int q = 0; q < 25; ++q) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + poff[q] * WC + 4 * (sl ^ (poff[q] & 15))) : z;
+        d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + pbase[q] + 4 * (sl ^ pxm[q])) : z;
       }
       float* g = vnext + ((long)tb * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
       // B^T d B on channel PAIRS (v_pk_*_f32: two channels per VALU instruction; no MFMA runs beside this)
+      // B^T x with shared subexpressions (9 packed operations instead of 15; small integers times f32: the
+      // association only moves the last bit, and every later layer's V comes from this one code path)
       auto bt5p = [](f32x2 x0, f32x2 x1, f32x2 x2, f32x2 x3, f32x2 x4, f32x2* r) {
-        r[0] = 2.f * x0 - x1 - 2.f * x2 + x3;
-        r[1] = 2.f * x1 + x2 - x3;
-        r[2] = -2.f * x1 + 3.f * x2 - x3;
         r[3] = x3 - x1;
-        r[4] = 2.f * x1 - x2 - 2.f * x3 + x4;
+        r[0] = 2.f * (x0 - x2) + r[3];
+        r[4] = (x4 - x2) - 2.f * r[3];
+        r[1] = 2.f * x1 + (x2 - x3);
+        r[2] = (3.f * x2 - x3) - 2.f * x1;
       };
       f32x2 vv[25][2];
 #pragma unroll
@@ -685,6 +714,12 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   const dim3 grid(8 * per_xcd), block(256);
 #ifdef AGZ_TIMING_EXPERIMENTS
   static const int xp = getenv("AGZ_WINO_X") ? atoi(getenv("AGZ_WINO_X")) : 0;
+  if (xp && y && vnext && res && split) {
+    auto kern = xp == 1 ? k_wino_gemm4<3, 1, true> : xp == 2 ? k_wino_gemm4<3, 2, true> : xp == 3 ? k_wino_gemm4<3, 3, true>
+              : xp == 5 ? k_wino_gemm4<3, 5, true> : k_wino_gemm4<3, 0, true>;
+    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    return;
+  }
   if (xp && y && vnext && res && !split) {
     auto kern = xp == 1 ? k_wino_gemm4<3, 1> : xp == 2 ? k_wino_gemm4<3, 2> : xp == 3 ? k_wino_gemm4<3, 3>
               : xp == 4 ? k_wino_gemm4<3, 4> : xp == 5 ? k_wino_gemm4<3, 5> : xp == 6 ? k_wino_gemm4<3, 6>
