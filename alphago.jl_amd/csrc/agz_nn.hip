@@ -560,8 +560,9 @@ void Net::pack() {
 }
 
 void Net::reserve(int bcap) {
-  if (precision_ == 1 && tower_ > 0 && d_ha_.n < (size_t)std::max(bcap, bcap_) * P_ * kC) {
-    const size_t n = (size_t)std::max(bcap, bcap_) * P_ * kC;
+  if (precision_ == 1 && tower_ > 0 && d_ha_.n < ((size_t)std::max(bcap, bcap_) * P_ + 256) * kC) {
+    // + one tile of rows: the persistent fp16 convolution stores whole 224-row tiles (agz_conv16.hip)
+    const size_t n = ((size_t)std::max(bcap, bcap_) * P_ + 256) * kC;
     d_ha_.alloc(n);
     d_hb_.alloc(n);
     d_ht_.alloc(n);
