@@ -92,7 +92,10 @@ __device__ __forceinline__ void glds16hs(const void* gbase_uniform, unsigned lan
 //   trickled through the LDS image instead of stored in a burst, 128-row tiles with two workgroups per CU (0.659 vs
 //   0.665 ms), non-temporal stores.  (An intermediate form with the weights in LDS -- 128 x 128 wave tiles, 48 KB
 //   weight groups by LDS-DMA -- ran its loop in 0.48 ms and 0.38 ms with the DMA compiled out: the DMA writes compete
-//   with the operand reads for the LDS port.)
+//   with the operand reads for the LDS port.)  Same lesson from the LDS side: the lanes that read the shared row of
+//   zeros make nearly every slab read a 2-way bank conflict (SQ_LDS_BANK_CONFLICT 0.36 of the LDS cycles); giving each
+//   lane zeros in the banks of its real address removes them (0.04) -- and the forward got 3 % SLOWER in an A/B on one
+//   box (14.15 -> 14.59 ms): fewer cycles, lower clock.  Not kept.
 constexpr int W2_RB_PRODUCT = 7;                    // row blocks per tile of the product form (224 rows)
 constexpr int W2_KS = HCH * 18;                     // k-steps per tile
 constexpr int W2_RR = 2;                            // epilogue passes of residual in flight (f32 residual: 1)
