@@ -106,6 +106,7 @@ class Net {
   DevBuf<float> d_uwino_s_, d_scale_s_;        // split form: weights as halves, scale x 1 / (operand scales)
   bool packed_split_ = false;
   DevBuf<float> d_uwino_, d_vimg_, d_vimg2_;   // transformed weights (stage images) / transformed activations (ping-pong)
+  DevBuf<float> d_ustem_, d_ustem_s_;          // the stem's transformed weights (8 stages), f32 / split form
   int precision_ = 0;
   bool packed16_ = false;
   DevBuf<uint16_t> d_wi16_;               // fp16 tower weights as padded LDS tile images [layer][stage 72][256][40]
@@ -149,18 +150,21 @@ void launch_conv3x3_direct(const float* x, const float* wt, const float* scale, 
                            float* y, const int* d_count, int bcap, int N, int relu, int cin_pad, hipStream_t s);
 
 // Winograd F(3x3,3x3) tower convolution (agz_wino.hip)
-void wino_pack_weights(const ConvHost& c, float* out);
-size_t wino_weight_floats();
+constexpr int kWinoStages = 64, kWinoStemStages = 8;   // K-loop stages (input channels / 4) of a tower layer / the stem
+void wino_pack_weights(const ConvHost& c, float* out, int ns = kWinoStages);
+size_t wino_weight_floats(int ns = kWinoStages);
 size_t wino_v_floats(int bcap, int T);
 // x -> V (the 25 transformed planes as GEMM stage images); needed in front of the first Winograd layer, and
 // in front of every layer when the board's tiles do not pack into whole-board tile blocks (!wino_fusable)
-void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s);
+void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s,
+                    int ns = kWinoStages);
 // V, U -> y (if y != NULL: affine, residual, ReLU applied) and / or the NEXT layer's V (if vnext != NULL)
 void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
-                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s);
+                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s,
+                      int ns = kWinoStages);
 bool wino_fusable(int N);
 // split-operand form (AGZ_PRECISION_F32S): weights as (hi, lo) halves of 2^10 u; 1 / (operand scales) for the epilogue
-void wino_pack_weights_split(const ConvHost& c, float* out);
+void wino_pack_weights_split(const ConvHost& c, float* out, int ns = kWinoStages);
 float wino_split_descale();
 
 // fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged

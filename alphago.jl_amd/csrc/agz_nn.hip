@@ -484,11 +484,15 @@ void Net::pack() {
     for (int l = 0; l < 2 * tower_; ++l) wino_pack_weights_split(tconv_[l], u.data() + uper * l);
     d_uwino_s_.ensure(u.size());
     AGZ_HIP(hipMemcpyAsync(d_uwino_s_.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    std::vector<float> sc((size_t)2 * tower_ * kC), tmp(kC);
-    for (int l = 0; l < 2 * tower_; ++l) {
-      bn_affine(tconv_[l], sc.data() + (size_t)l * kC, tmp.data());
+    std::vector<float> sc((size_t)(2 * tower_ + 1) * kC), tmp(kC);
+    for (int l = 0; l <= 2 * tower_; ++l) {        // the stem's comes last
+      bn_affine(l < 2 * tower_ ? tconv_[l] : stem_, sc.data() + (size_t)l * kC, tmp.data());
       for (int o = 0; o < kC; ++o) sc[(size_t)l * kC + o] *= wino_split_descale();        // a power of two: exact
     }
+    std::vector<float> us(wino_weight_floats(kWinoStemStages));
+    wino_pack_weights_split(stem_, us.data(), kWinoStemStages);
+    d_ustem_s_.ensure(us.size());
+    AGZ_HIP(hipMemcpyAsync(d_ustem_s_.p, us.data(), us.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
     d_scale_s_.ensure(sc.size());
     AGZ_HIP(hipMemcpyAsync(d_scale_s_.p, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
     AGZ_HIP(hipStreamSynchronize(stream_));
@@ -532,6 +536,10 @@ void Net::pack() {
     for (int l = 0; l < 2 * tower_; ++l) wino_pack_weights(tconv_[l], u.data() + uper * l);
     d_uwino_.ensure(u.size());
     AGZ_HIP(hipMemcpyAsync(d_uwino_.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    std::vector<float> us(wino_weight_floats(kWinoStemStages));
+    wino_pack_weights(stem_, us.data(), kWinoStemStages);
+    d_ustem_.ensure(us.size());
+    AGZ_HIP(hipMemcpyAsync(d_ustem_.p, us.data(), us.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
     AGZ_HIP(hipStreamSynchronize(stream_));
   }
   auto up = [&](DevBuf<float>& d, const std::vector<float>& h) {
@@ -599,8 +607,13 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
   float *a = d_a_.p, *b = d_b_.p, *t = d_t_.p;
   if (prof_on_ && prof_fwd_ < kProfMax)
     (void)hipMemcpyAsync(&prof_counts_[prof_fwd_], d_count, sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
-  hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad>), dim3(grid), dim3(256), 0, stream_, d_x32, d_wstem_.p,
-                     d_scale_.p, d_shift_.p, (const float*)nullptr, a, d_count, N_, 1);
+  // The stem goes through the Winograd GEMM too when the tower does (8 K-loop stages for its 17 -> 32 padded input
+  // planes instead of a direct convolution over K = 9 x 32): its epilogue then also emits the first tower layer's V,
+  // and the one k_wino_in per forward shrinks to the 32-channel feature planes.
+  const bool stem_wino = precision_ != 1 && winograd_ && tower_ > 0;
+  if (!stem_wino)
+    hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad>), dim3(grid), dim3(256), 0, stream_, d_x32, d_wstem_.p,
+                       d_scale_.p, d_shift_.p, (const float*)nullptr, a, d_count, N_, 1);
   // every tower-conv launch goes through here so that bench.py's HIP-event roofline leg sees it
   auto timed = [&](auto&& launch) {
     const bool p = prof_on_ && prof_n_ < kProfMax;
@@ -644,11 +657,15 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       // k_wino_in; conv1 of a block leaves nothing but V in HBM, conv2 leaves the block output (the next residual,
       // and the heads' input) and the next block's V
       float *vcur = d_vimg_.p, *vnxt = d_vimg2_.p;
+      if (stem_wino) {
+        launch_wino_in(d_x32, vnxt, d_count, bcap, N_, split, stream_, kWinoStemStages);
+        launch_wino_gemm(vnxt, split ? d_ustem_s_.p : d_ustem_.p, split ? d_scale_s_.p + (size_t)2 * tower_ * kC : d_scale_.p,
+                         d_shift_.p, nullptr, a, vcur, d_count, bcap, N_, 1, split, stream_, kWinoStemStages);
+      }
       for (int blk = 0; blk < tower_; ++blk) {     // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32
         const int l1 = 2 * blk, l2 = 2 * blk + 1;
         const bool last = blk + 1 == tower_;
         timed([&] {
-          if (blk == 0) launch_wino_in(a, vcur, d_count, bcap, N_, split, stream_);
           launch_wino_gemm(vcur, usrc + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, nullptr, vnxt,
                            d_count, bcap, N_, 1, split, stream_);
         });
@@ -659,6 +676,12 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         std::swap(a, b);
       }
     } else {
+      if (stem_wino) {
+        launch_wino_in(d_x32, d_vimg_.p, d_count, bcap, N_, split, stream_, kWinoStemStages);
+        launch_wino_gemm(d_vimg_.p, split ? d_ustem_s_.p : d_ustem_.p,
+                         split ? d_scale_s_.p + (size_t)2 * tower_ * kC : d_scale_.p, d_shift_.p, nullptr, a, nullptr, d_count,
+                         bcap, N_, 1, split, stream_, kWinoStemStages);
+      }
       auto conv = [&](int l, const float* in, const float* res, float* out) {
         timed([&] {
           if (winograd_) {

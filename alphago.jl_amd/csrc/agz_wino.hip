@@ -44,6 +44,7 @@ constexpr int WT = 64;            // tiles per workgroup
 constexpr int WC = 64;            // output channels per workgroup
 constexpr int WK = 4;             // input channels per stage
 constexpr int WNS = kC / WK;      // 64 stages
+static_assert(WNS == kWinoStages && kCinStemPad == kWinoStemStages * WK, "stage counts of agz_nn.h");
 constexpr int WXI = 25;
 constexpr int WPL = 13;           // LDS row planes: a row holds the 4 channels of TWO transform planes
 constexpr int A_STAGE = WPL * WT * 8;    // floats (26,624 B)
@@ -114,7 +115,8 @@ __device__ __forceinline__ void bt5(float x0, float x1, float x2, float x3, floa
 // chunks of 32 rows x 16 B) and leave for HBM as whole 512-byte runs, 16 B per lane.  The LDS copies of the four
 // stages are skewed by 8 dwords each: a ds_write_b64 is served 16 lanes (2 tiles x 8 lanes) at a time over 32
 // banks, and with that skew the 16 lanes cover all 32 banks exactly once.
-template <int TPB, bool NT, bool SPLIT = false>
+// NS = stages = input channels / 4: 64 for a tower layer, 8 for the stem (17 feature planes padded to 32)
+template <int TPB, bool NT, bool SPLIT = false, int NS = WNS>
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T) {
   static_assert(TPB == 32, "the copy-out below moves 32-row chunks");
@@ -143,16 +145,16 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
     for (int v = 0; v < 5; ++v) {
       const int pi = 3 * ti - 1 + u, pj = 3 * tj - 1 + v;
       const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
-      off[u * 5 + v] = ok ? (b * P + pi + N * pj) * kC : -1;
+      off[u * 5 + v] = ok ? (b * P + pi + N * pj) * (NS * WK) : -1;
     }
   // f32 form: this thread's channel pair is an 8-byte slot of the row; split form: two 4-byte slots (hi pair, lo pair)
   float* mine = img + sl * IMG + tl * 4 + (SPLIT ? 0 : 2 * ((h + (row >> 4)) & 1));
   // the unused plane slot 25 (chunk 25) is copied out with the rest: keep it finite
   if (SPLIT) { mine[25 * CH + h] = 0.f; mine[25 * CH + 2 + h] = 0.f; }
   else *reinterpret_cast<float2*>(mine + 25 * CH) = make_float2(0.f, 0.f);
-  float* gdst = vimg + (long)tb * WNS * A_STAGE + part * CH;
+  float* gdst = vimg + (long)tb * NS * A_STAGE + part * CH;
   const int cq = threadIdx.x / TPB, cl = threadIdx.x % TPB;      // copy-out: 8 chunks per round, 32 lanes each
-  for (int sg = 0; sg < WNS / SP; ++sg) {
+  for (int sg = 0; sg < NS / SP; ++sg) {
     const int st = sg * SP + sl;
     float2 d[25];
 #pragma unroll
@@ -263,7 +265,8 @@ constexpr int IMG_FLOATS = WT * 9 * WC;          // 147,456 B
 // X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
 //   1 = K loop only; 2 = no epilogue 2; 3 = epilogue 2 without its global stores; 4 = no DMA after the prologue;
 //   5 = no MFMA; 6 = no LDS operand reads
-template <int MODE, int X = 0, bool SPLIT = false>
+// NS: stages of the K loop (input channels / 4): 64, or 8 for the stem
+template <int MODE, int X = 0, bool SPLIT = false, int NS = WNS>
 __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
@@ -284,8 +287,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
-  const float* asrc = vimg + (long)tb * WNS * A_STAGE;
-  const float* bsrc = uimg + (long)cb * WNS * B_STAGE;
+  const float* asrc = vimg + (long)tb * NS * A_STAGE;
+  const float* bsrc = uimg + (long)cb * NS * B_STAGE;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0];
 
   // a stage is 52 chunks of 1 KB: 0..25 from V, 26..51 from U; wave w moves the 13 consecutive chunks 13 w ..
@@ -408,9 +411,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     }
     buf = nbuf;
   };
-  for (int st = 0; st < WNS - 2; ++st) stage(st, std::true_type{}, std::true_type{});
-  stage(WNS - 2, std::false_type{}, std::true_type{});
-  stage(WNS - 1, std::false_type{}, std::false_type{});
+  for (int st = 0; st < NS - 2; ++st) stage(st, std::true_type{}, std::true_type{});
+  stage(NS - 2, std::false_type{}, std::true_type{});
+  stage(NS - 1, std::false_type{}, std::false_type{});
 
   // the asm MFMAs' D registers -> VALU readers below: 18 wait states.  The pad must NAME those registers, or the
   // scheduler is free to lift a register-only VALU read of them above it (seen: 4e-4 errors on some lanes)
@@ -637,11 +640,11 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 // Flux [kw,kh,cin,cout] column-major -> stage images U[cout block][stage][plane][cout 64][8] with
 // U_xi = G k G^T computed in float64.  k is the CORRELATION kernel: NNlib's conv is a true
 // convolution, so tap (a', b') reading x[i + a' - 1, j + b' - 1] carries w[2 - a', 2 - b'].
-void wino_pack_weights(const ConvHost& c, float* out) {
+void wino_pack_weights(const ConvHost& c, float* out, int ns) {
   static const double G[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6, -1.0 / 6, 1.0 / 6},
                                  {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
   const int cin = c.cin, cout = c.cout;
-  std::memset(out, 0, sizeof(float) * wino_weight_floats());
+  std::memset(out, 0, sizeof(float) * wino_weight_floats(ns));
   for (int o = 0; o < cout; ++o)
     for (int ci = 0; ci < cin; ++ci) {
       double k[3][3];
@@ -655,17 +658,17 @@ void wino_pack_weights(const ConvHost& c, float* out) {
             for (int b = 0; b < 3; ++b) u += G[i][a] * k[a][b] * G[j][b];
           const int xi = i * 5 + j;
           const int pos = 2 * wino_pair_pos(ol, xi, cl >> 1) + (cl & 1);
-          out[(((size_t)cb * WNS + st) * WPL + (xi >> 1)) * WC * 8 + (size_t)ol * 8 + pos] = (float)u;
+          out[(((size_t)cb * ns + st) * WPL + (xi >> 1)) * WC * 8 + (size_t)ol * 8 + pos] = (float)u;
         }
     }
 }
 
 // the same in the split form: u' = 2^10 u as (hi, lo) halves, rows laid out by wino_v_off (block h = 0: hi, 1: lo)
-void wino_pack_weights_split(const ConvHost& c, float* out) {
+void wino_pack_weights_split(const ConvHost& c, float* out, int ns) {
   static const double G[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6, -1.0 / 6, 1.0 / 6},
                                  {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
   const int cin = c.cin, cout = c.cout;
-  std::memset(out, 0, sizeof(float) * wino_weight_floats());
+  std::memset(out, 0, sizeof(float) * wino_weight_floats(ns));
   _Float16* o16 = reinterpret_cast<_Float16*>(out);
   for (int o = 0; o < cout; ++o)
     for (int ci = 0; ci < cin; ++ci) {
@@ -681,7 +684,7 @@ void wino_pack_weights_split(const ConvHost& c, float* out) {
           const int xi = i * 5 + j;
           _Float16 hi, lo;
           split_half((float)(u * (double)kSplitU), hi, lo);
-          const size_t base = ((size_t)cb * WNS + st) * B_STAGE;       // floats
+          const size_t base = ((size_t)cb * ns + st) * B_STAGE;       // floats
           o16[2 * (base + wino_v_off(xi, ol, 0)) + cl] = hi;
           o16[2 * (base + wino_v_off(xi, ol, 1)) + cl] = lo;
         }
@@ -689,7 +692,7 @@ void wino_pack_weights_split(const ConvHost& c, float* out) {
 }
 float wino_split_descale() { return 1.f / (kSplitV * kSplitU); }
 
-size_t wino_weight_floats() { return (size_t)(kC / WC) * WNS * B_STAGE; }
+size_t wino_weight_floats(int ns) { return (size_t)(kC / WC) * ns * B_STAGE; }
 static long wino_blocks(int bcap, int T) {
   const long rpb = wino_rows_per_block(T);
   return ((long)bcap * T * T + rpb - 1) / rpb;
@@ -697,9 +700,14 @@ static long wino_blocks(int bcap, int T) {
 size_t wino_v_floats(int bcap, int T) { return (size_t)wino_blocks(bcap, T) * WNS * A_STAGE; }
 bool wino_fusable(int N) { return wino_whole_boards((N + 2) / 3); }
 
-void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s) {
+void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s, int ns) {
   const int T = (N + 2) / 3;
   const int blocks = (int)wino_blocks(bcap, T);
+  if (ns == kWinoStemStages) {
+    if (split) hipLaunchKernelGGL((k_wino_in<32, true, true, kWinoStemStages>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+    else hipLaunchKernelGGL((k_wino_in<32, true, false, kWinoStemStages>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+    return;
+  }
   if (split) hipLaunchKernelGGL((k_wino_in<32, true, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
   else hipLaunchKernelGGL((k_wino_in<32, true, false>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
 }
@@ -707,11 +715,22 @@ void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, i
 // y == nullptr: the activations are not needed in HBM (only their transform is); vnext == nullptr: no next
 // Winograd layer (or a board size whose tile blocks do not hold whole boards: wino_fusable(N) is false)
 void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
-                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s) {
+                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s, int ns) {
   const int T = (N + 2) / 3;
   const int blocks = (int)wino_blocks(bcap, T);
   const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm4
   const dim3 grid(8 * per_xcd), block(256);
+  if (ns == kWinoStemStages) {                   // the stem: its output is always wanted in HBM (block 0's residual)
+    constexpr int S = kWinoStemStages;
+    if (split) {
+      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, 0, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+      else hipLaunchKernelGGL((k_wino_gemm4<1, 0, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    } else {
+      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, 0, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+      else hipLaunchKernelGGL((k_wino_gemm4<1, 0, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    }
+    return;
+  }
 #ifdef AGZ_TIMING_EXPERIMENTS
   static const int xp = getenv("AGZ_WINO_X") ? atoi(getenv("AGZ_WINO_X")) : 0;
   if (xp && y && vnext && res && split) {
