@@ -38,7 +38,8 @@ for k, cs in agg.items():
     # bytes summed over every dispatch of the run; a tower layer = one GEMM dispatch (k_wino_in runs once per forward)
     per_kernel[k] = {c: 1024.0 * sum(v) for c, v in cs.items()}
     counts[k] = max(len(v) for v in cs.values())
-    if "gemm" in k or "conv3x3_f16" in k:
+    stem = k.rstrip().endswith(", 8>")          # the stem's 8-stage GEMM and its feature-plane transform: listed, not counted
+    if ("gemm" in k or "conv3x3_f16" in k) and not stem:
         layers += counts[k]
     # MI355X_MICROARCH.md, HBM: "FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane,
     # global_load and buffer_load ... lds alike) -- double it before comparing with a byte count".  Every read of these
@@ -46,12 +47,13 @@ for k, cs in agg.items():
     if "FETCH_SIZE" in per_kernel[k]:
         per_kernel[k]["FETCH_SIZE_raw"] = per_kernel[k]["FETCH_SIZE"]
         per_kernel[k]["FETCH_SIZE"] *= 2.0
-    total += sum(v for c, v in per_kernel[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE"))
+    if not stem:
+        total += sum(v for c, v in per_kernel[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE"))
 layers = max(layers, 1)
 print(json.dumps({
     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/nn_micro.py --batches {B}, gfx950; KiB counters; "
               "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads (raw kept); bytes of ALL "
-              "Winograd kernels of the run / number of tower-layer GEMM dispatches",
+              "tower-layer Winograd kernels of the run / number of tower-layer GEMM dispatches (the stem's 8-stage GEMM is listed, not counted)",
     "rows_per_launch": rows, "tower_layer_dispatches": layers, "bytes_per_launch": total / layers, "bytes_per_row": total / layers / rows,
     "algorithmic_bytes_per_row": 2.5 * 256 * 4,
     "per_kernel_total_bytes": per_kernel, "per_kernel_dispatches": counts,
