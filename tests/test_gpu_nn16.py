@@ -68,6 +68,35 @@ def test_f16_forward_matches_oracle(N, tower, B):
     eng.close()
 
 
+@pytest.mark.parametrize("N,B", [(3, 25), (4, 14), (4, 15), (6, 70), (13, 9), (16, 8), (9, 300)])
+def test_f16_tile_geometry(N, B):
+    """the persistent fp16 convolution works on 224-row tiles of consecutive board points: batches that end exactly
+    on a tile (4x4 x 14 = 224 rows), one row past it, well inside one, across several workgroups' second tiles
+    (9x9 x 300 = 108 tiles... of 256 CUs: one each; the full batch of test_gpu_nn.py gives every workgroup 11-12),
+    and halos of every size class (N + 1 = 4 .. 17 rows).  Bars as in test_f16_forward_matches_oracle."""
+    tower = 2
+    A = N * N + 1
+    rng = np.random.RandomState(100 + N)
+    onet = L.or_net_new(N, tower)
+    L.or_net_init_synthetic(onet, 3)
+    randomize_bn(onet, list(range(0, 1 + 2 * tower)) + [orc.L_VALUE_CONV, orc.L_POLICY_CONV], rng)
+    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    copy_weights_from_oracle(eng, onet, tower)
+    eng.set_precision("f16")
+    feats = (rng.rand(B, 17 * N * N) < 0.3).astype(np.float32)
+    feats[:, 16 * N * N:] = np.where(rng.rand(B, 1) < 0.5, 1.0, -1.0)
+    pi16, v16 = np.zeros((B, A), np.float32), np.zeros(B, np.float32)
+    L.or_net_forward_feats(onet, orc.fptr(feats), B, orc.fptr(pi16), orc.fptr(v16), 16)
+    gpi, gv = eng.forward_features(feats)
+    d16 = max(np.abs(gpi - pi16).max(), np.abs(gv - v16).max())
+    assert d16 <= TOL16, d16
+    for k in (0, B // 2, B - 1):                                   # a row's result does not depend on its tile
+        spi, sv = eng.forward_features(feats[k:k + 1])
+        assert (spi[0] == gpi[k]).all() and sv[0] == gv[k], k
+    L.or_net_free(onet)
+    eng.close()
+
+
 @pytest.mark.parametrize("N,tower,readouts,games,slots", [(5, 2, 16, 4, 4), (9, 2, 24, 2, 2)])
 def test_f16_selfplay_games_match_oracle(N, tower, readouts, games, slots):
     eng = ag.Engine(board_size=N, tower_height=tower, games=slots, num_readouts=readouts, seed=6,
