@@ -188,6 +188,7 @@ def load():
         "agz_tree_set_draw": (i32, [E, i32, u64, u32]),
         "agz_debug_draws": (i32, [E, u64, u64, u32, i32, f64, f64p]),
         "agz_debug_math": (i32, [E, i32, f64p, f64p, i32, f64p]),
+        "agz_debug_counters": (i32, [E, C.POINTER(C.c_uint64), i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

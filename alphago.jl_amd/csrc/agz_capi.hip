@@ -540,5 +540,10 @@ agz_status agz_debug_draws(agz_engine* e, uint64_t seed, uint64_t game, uint32_t
 agz_status agz_debug_math(agz_engine* e, int32_t op, const double* x, const double* y, int32_t n, double* out) {
   return guard(e, [&](agz::Engine& E) { E.debug_math(op, x, y, n, out); });
 }
+int32_t agz_debug_counters(agz_engine* e, uint64_t* out, int32_t cap) {
+  int32_t n = -1;
+  (void)guard(e, [&](agz::Engine& E) { n = E.debug_counters(out, cap); });
+  return n;
+}
 
 }  // extern "C"

@@ -30,6 +30,7 @@ class Engine {
   void start(int64_t total_games);
   void step(int nsteps);
   void stats(agz_stats* out);
+  int debug_counters(uint64_t* out, int cap);
   int select_external();
   void leaf_features_external(float* feats_out);
   void incorporate_external(const float* pi, const float* v);

@@ -61,6 +61,10 @@ struct HipWave {
     return v;
   }
   __device__ __forceinline__ bool any(bool v) const { return __any(v) != 0; }
+  __device__ __forceinline__ unsigned long long clock() const { return wall_clock64(); }     // 100 MHz
+  __device__ __forceinline__ void count_max(unsigned long long* p, unsigned long long v) const {
+    if (lane == 0) atomicMax(p, v);
+  }
   // append every get(i) >= 0, i ascending, to a downward stack (base[--sp]); returns the new sp
   template <class F>
   __device__ __forceinline__ int push_desc(int n, F get, int32_t* base, int sp) const {
@@ -519,6 +523,14 @@ void Engine::incorporate_external(const float* pi, const float* v) {
   AGZ_HIP(hipStreamSynchronize(stream_));
   external_batch_ = 0;
   external_batch2_ = 0;
+}
+
+int Engine::debug_counters(uint64_t* out, int cap) {
+  unsigned long long c[CT_COUNT];
+  AGZ_HIP(hipMemcpyAsync(c, V_.counters, sizeof(c), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  for (int i = 0; i < CT_COUNT && i < cap; ++i) out[i] = c[i];
+  return CT_COUNT;
 }
 
 void Engine::stats(agz_stats* out) {

@@ -36,6 +36,23 @@
 #define AGZ_FN inline
 #endif
 
+// k_pre phase clocks (timing builds only; see CT_T_* in agz_state.h)
+#ifdef AGZ_TIMING_EXPERIMENTS
+#define AGZ_STAMP_BEGIN(w) unsigned long long agz_t_prev = (w).clock()
+#define AGZ_STAMP_BEGIN_AGAIN(w) agz_t_prev = (w).clock()
+#define AGZ_STAMP(w, V, slot)                                   \
+  do {                                                          \
+    const unsigned long long agz_t_now = (w).clock();           \
+    (w).count(&(V).counters[slot], agz_t_now - agz_t_prev);      \
+    agz_t_prev = agz_t_now;                                     \
+  } while (0)
+#else
+#define AGZ_STAMP_BEGIN(w) unsigned long long agz_t_prev = 0
+#define AGZ_STAMP_BEGIN_AGAIN(w) (void)agz_t_prev
+#define AGZ_STAMP(w, V, slot) (void)agz_t_prev
+#endif
+
+
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -383,6 +400,7 @@ AGZ_FN int node_create_child(W& w, const View& V, Scratch& S, int g, int parent,
   const NodeMeta pm = V.meta[pi];
   const int P = V.P, N = V.N;
   if (a < 0 || a >= V.A || !legal_bit(V, pi, a)) return -2;
+  AGZ_STAMP_BEGIN(w);
   const int id = pool_alloc(w, V, S, g);
   if (id < 0) return -1;
   NodeMeta m;
@@ -413,6 +431,10 @@ AGZ_FN int node_create_child(W& w, const View& V, Scratch& S, int g, int parent,
   node_init_from_scratch(w, V, S, g, id, m);
   if (w.leader()) V.child[pi * V.AP + a] = id;
   w.sync();
+  AGZ_STAMP(w, V, CT_T_CREATE);
+#ifdef AGZ_TIMING_EXPERIMENTS
+  w.count(&V.counters[CT_N_CREATE], 1);
+#endif
   return id;
 }
 
@@ -807,6 +829,7 @@ AGZ_FN void game_move_phase(W& w, const View& V, Scratch& S, int g) {
     game_finish(w, V, S, g, -rm.to_play, 1, 0.f);
     return;
   }
+  AGZ_STAMP_BEGIN(w);
   int a = V.P;
   if (pick_move(w, V, S, g, &a) != AGZ_OK) a = V.P;  // the reference dies on its assertion; we pass
   // play_move!(player, c): record pi and Q, then re-root (mcts_play.jl:26-50)
@@ -819,9 +842,11 @@ AGZ_FN void game_move_phase(W& w, const View& V, Scratch& S, int g) {
     }
   }
   w.sync();
+  AGZ_STAMP(w, V, CT_T_PICK);
   int child = V.child[ri * V.AP + a];
   if (child < 0) child = node_create_child(w, V, S, g, root, a);
   if (child < 0) { game_finish(w, V, S, g, 0, 0, 0.f); return; }
+  AGZ_STAMP(w, V, CT_T_CHILD);
   reroot(w, V, S, g, a, child);
   if (w.leader()) { G.move_count = k + 1; G.nqs = k + 1; }
   w.sync();
@@ -829,6 +854,7 @@ AGZ_FN void game_move_phase(W& w, const View& V, Scratch& S, int g) {
   w.sync();
   if (w.leader()) G.short_first = 0;
   w.sync();
+  AGZ_STAMP(w, V, CT_T_REROOT);
   if (node_is_done(V, g, child)) {
     load_board(w, V, S, node_index(V, g, child));
     const float sc = area_score(w, V, S, G.komi);
@@ -838,6 +864,7 @@ AGZ_FN void game_move_phase(W& w, const View& V, Scratch& S, int g) {
   inject_noise(w, V, S, g, child);
   if (w.leader()) G.target = G.rootN + (float)V.R;
   w.sync();
+  AGZ_STAMP(w, V, CT_T_NOISE);
 }
 
 // Record which boards feed the eight history planes of leaf `k` (features.jl:8-14): path
@@ -1051,14 +1078,21 @@ AGZ_FN void arena_move_phase(W& w, const View& V, Scratch& S, int g) {
 template <class W>
 AGZ_FN void game_pre(W& w, const View& V, Scratch& S, int g) {
   GameState& G = V.gs[g];
+  AGZ_STAMP_BEGIN(w);
+  const unsigned long long agz_t_start = agz_t_prev;
+  (void)agz_t_start;
   if (G.garbage > 0 && G.phase != G_MANUAL) free_pending(w, V, S, g, kFreeBudget);
+  AGZ_STAMP(w, V, CT_T_FREE);
   if (V.arena && G.phase != G_MANUAL) { arena_pre(w, V, S, g); return; }
   if (G.phase == G_MANUAL || G.phase == G_RETIRED) {
     if (w.leader() && G.phase == G_RETIRED) G.nleaves = 0;
     w.sync();
     return;
   }
-  if (G.phase == G_SEARCH && !(G.rootN < G.target)) game_move_phase(w, V, S, g);
+  bool agz_moved = false;
+  if (G.phase == G_SEARCH && !(G.rootN < G.target)) { game_move_phase(w, V, S, g); agz_moved = true; }
+  (void)agz_moved;
+  AGZ_STAMP_BEGIN_AGAIN(w);
   if (G.phase == G_IDLE) {
     if (w.leader()) G.nleaves = 0;
     w.sync();
@@ -1082,7 +1116,15 @@ AGZ_FN void game_pre(W& w, const View& V, Scratch& S, int g) {
     w.count(&V.counters[CT_EVALS], 1);
     return;
   }
-  if (G.phase == G_SEARCH) game_select_phase(w, V, S, g, V.par);
+  if (G.phase == G_SEARCH) {
+    game_select_phase(w, V, S, g, V.par);
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const unsigned long long t = w.clock();
+    w.count(&V.counters[agz_moved ? CT_T_MOVE_SELECT : CT_T_SELECT], t - agz_t_prev);
+    w.count(&V.counters[agz_moved ? CT_N_MOVE : CT_N_SELECT], 1);
+    if (agz_moved) w.count_max(&V.counters[CT_T_MOVE_MAX], t - agz_t_start);
+#endif
+  }
 }
 
 // Phase C: revert virtual losses and incorporate the network outputs in collection order

@@ -68,6 +68,11 @@ enum Counter : int {
   CT_STEPS = 0, CT_POSITIONS, CT_STARTED, CT_FINISHED, CT_EVALS, CT_DUP, CT_TERMINAL, CT_ROOTVISITS,
   CT_POOL_EXHAUSTED, CT_RESIGNED, CT_CLAIMED,
   CT_RECORDED,     // records written to the finished-game ring since the last records_clear (CT_FINISHED never resets)
+  // k_pre phase clocks (100 MHz ticks summed over games), written only in -DAGZ_TIMING_EXPERIMENTS builds and read
+  // through agz_debug_counters (tools/pre_phases.py): games in their per-move phase / all searching games
+  CT_T_FREE, CT_T_PICK, CT_T_CHILD, CT_T_REROOT, CT_T_NOISE, CT_T_MOVE_SELECT, CT_N_MOVE, CT_T_SELECT, CT_N_SELECT,
+  CT_T_MOVE_MAX,   // max over games of one move phase + its select phase
+  CT_T_CREATE, CT_N_CREATE,   // node_create_child (leaf expansion: board update in scratch), all callers
   CT_COUNT
 };
 

@@ -20,6 +20,10 @@ agz_status agz_debug_draws(agz_engine* e, uint64_t seed, uint64_t game, uint32_t
  * 4: (double)((float)x / (float)y) 5: PUCT score of (W=x, N=y, P=0.25, to_play=-1, N_node=y+7) */
 agz_status agz_debug_math(agz_engine* e, int32_t op, const double* x, const double* y, int32_t n,
                           double* out);
+/* The engine's raw device counters (enum Counter of agz_state.h), including the k_pre phase clocks that only a
+ * -DAGZ_TIMING_EXPERIMENTS build of libagz.so writes (tools/pre_phases.py); returns how many there are, copies
+ * min(cap, that) of them.  Synchronises. */
+int32_t agz_debug_counters(agz_engine* e, uint64_t* out, int32_t cap);
 
 #ifdef __cplusplus
 }

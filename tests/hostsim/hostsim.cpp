@@ -40,6 +40,8 @@ struct SimWave {
   void amax(int32_t* p, int v) const { if (v > *p) *p = v; }
   void aor(int32_t* p, int v) const { *p |= v; }
   void count(unsigned long long* p, unsigned long long v) const { *p += v; }
+  unsigned long long clock() const { return 0; }
+  void count_max(unsigned long long* p, unsigned long long v) const { if (v > *p) *p = v; }
   unsigned long long fetch_add(unsigned long long* p, unsigned long long v) const {
     const unsigned long long old = *p;
     *p += v;

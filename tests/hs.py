@@ -191,7 +191,7 @@ class Sim:
         return B
 
     def counters(self):
-        out = (C.c_ulonglong * len(CT))()
+        out = (C.c_ulonglong * 64)()            # enum Counter of agz_state.h is longer than the names kept here
         self.L.hs_counters(self.h, out)
         return dict(zip(CT, list(out)))
 
