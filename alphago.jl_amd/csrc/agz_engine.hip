@@ -110,6 +110,16 @@ __global__ __launch_bounds__(kWave) void k_pre(View V) {
   game_pre(w, V, S, (int)blockIdx.x);
 }
 
+// the board updates of the leaves k_pre created (node_create_child, defer): one wave per leaf
+__global__ __launch_bounds__(kWave) void k_expand(View V) {
+  AGZ_SCRATCH(S)
+  HipWave w;
+  const int half = kMaxPend / 2;                 // a game rarely creates more than parallel_readouts leaves per step
+  const int g = (int)blockIdx.x / half, i = (int)blockIdx.x % half;
+  game_expand(w, V, S, g, i);
+  game_expand(w, V, S, g, i + half);
+}
+
 __global__ __launch_bounds__(kWave) void k_post(View V) {
   AGZ_SCRATCH(S)
   HipWave w;
@@ -403,6 +413,7 @@ Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
               "device %d is %s; libagz is built for gfx950 (MI355X) only", cfg.device, prop.gcnArchName);
   AGZ_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   fill_dims(V_, cfg);
+  V_.defer_expand = 1;      // k_expand follows every k_pre (step, select_external)
   AGZ_REQUIRE(V_.PP <= kPPMax && V_.AP <= kAPMax && V_.maxd <= kMaxdMax, AGZ_BAD_ARGUMENT, "board too large");
   for_each_buffer(V_, [&](auto*& p, size_t n) {
     using T = std::remove_reference_t<decltype(*p)>;
@@ -463,6 +474,7 @@ void Engine::step(int nsteps) {
               "engine was created with external_network=1: use select/incorporate");
   for (int s = 0; s < nsteps; ++s) {
     hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
+    hipLaunchKernelGGL(k_expand, dim3(V_.games * (kMaxPend / 2)), dim3(kWave), 0, stream_, V_);
     hipLaunchKernelGGL(cfg_.arena_mode ? k_scan_arena : k_scan, dim3(1), dim3(256), 0, stream_, V_);
     hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWave), 0, stream_, V_, 0, d_x32_.p, (float*)nullptr);
     if (cfg_.arena_mode) {   // evaluate(): Black's players ask network 0, White's network 1
@@ -480,6 +492,7 @@ void Engine::step(int nsteps) {
 
 int Engine::select_external() {
   hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
+  hipLaunchKernelGGL(k_expand, dim3(V_.games * (kMaxPend / 2)), dim3(kWave), 0, stream_, V_);
   hipLaunchKernelGGL(cfg_.arena_mode ? k_scan_arena : k_scan, dim3(1), dim3(256), 0, stream_, V_);
   int32_t n[2] = {0, 0};
   AGZ_HIP(hipMemcpyAsync(n, V_.batch_count, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, stream_));

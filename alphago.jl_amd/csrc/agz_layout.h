@@ -38,6 +38,7 @@ inline void fill_dims(View& V, const agz_config& c) {
   V.resign_threshold = c.resign_threshold;
   V.resign_disable_frac = c.resign_disable_fraction;
   V.komi = c.komi;
+  V.defer_expand = 0;
 }
 
 // visits every buffer of the View: f(pointer-reference, element count)
@@ -61,6 +62,7 @@ inline void for_each_buffer(View& V, F&& f) {
   f(V.leaf_tp, leaves);
   f(V.leaf_plen, leaves);
   f(V.leaf_path, leaves * V.maxd);
+  f(V.pend_node, (size_t)V.games * kMaxPend);
   f(V.rec_moves, (size_t)V.games * mgl);
   f(V.rec_pi, (size_t)V.games * mgl * V.A);
   f(V.rec_q, (size_t)V.games * mgl);

@@ -392,13 +392,38 @@ AGZ_FN void node_init_from_scratch(W& w, const View& V, Scratch& S, int g, int i
   write_legal_mask(w, V, S, ni, m.to_play, m.ko);
 }
 
-// play_move!(position, a) into a fresh node (board.jl:451-509 / pass_move! :426-440).
-// Returns the new node id, -1 on pool exhaustion, -2 on an illegal move.
+// The board half of node_create_child: play the node's move (meta.fmove) on its parent's board in scratch and
+// initialise the node's rows, board and legal mask from the result (board.jl:451-509 / pass_move! :426-440).
 template <class W>
-AGZ_FN int node_create_child(W& w, const View& V, Scratch& S, int g, int parent, int a) {
+AGZ_FN void node_expand_child(W& w, const View& V, Scratch& S, int g, int id) {
+  const long ni = node_index(V, g, id);
+  NodeMeta m = V.meta[ni];
+  const long pi = node_index(V, g, m.parent);
+  const NodeMeta pm = V.meta[pi];
+  const int a = m.fmove;
+  load_board(w, V, S, pi);
+  if (a != V.P) {
+    const int color = pm.to_play;
+    label_components(w, V, S, true);
+    group_liberties(w, V, S);
+    int ncap = 0, ko = -1;
+    apply_move_in_scratch(w, V, S, a, color, &ncap, &ko);
+    m.ko = ko;
+    if (pm.to_play == 1) m.caps_b += ncap; else m.caps_w += ncap;
+  }
+  node_init_from_scratch(w, V, S, g, id, m);
+}
+
+// play_move!(position, a) into a fresh node.  Returns the new node id, -1 on pool exhaustion, -2 on an illegal move.
+// defer (View::defer_expand, the engine's select phase): only allocate the node and link it -- nothing in the rest of
+// the select phase looks at a new, unexpanded leaf's board, rows or legal mask -- and leave node_expand_child to
+// k_expand, which runs one wave per new leaf instead of eight expansions in a row per game (21.7 us each: 62 % of the
+// select phase).  Terminal children are finished at once: their board is scored right after the descent.
+template <class W>
+AGZ_FN int node_create_child(W& w, const View& V, Scratch& S, int g, int parent, int a, bool defer = false) {
   const long pi = node_index(V, g, parent);
   const NodeMeta pm = V.meta[pi];
-  const int P = V.P, N = V.N;
+  const int P = V.P;
   if (a < 0 || a >= V.A || !legal_bit(V, pi, a)) return -2;
   AGZ_STAMP_BEGIN(w);
   const int id = pool_alloc(w, V, S, g);
@@ -410,32 +435,35 @@ AGZ_FN int node_create_child(W& w, const View& V, Scratch& S, int g, int parent,
   m.last_move = (int16_t)a;
   m.losses = 0;
   m.to_play = (int8_t)-pm.to_play;
-  m.flags = 0;
+  m.flags = NF_ALLOC;
   m.caps_b = pm.caps_b;
   m.caps_w = pm.caps_w;
   m.ko = -1;
   m.pad = 0;
-  load_board(w, V, S, pi);
-  if (a == P) {
-    // pass: done iff the previous move was a pass too
-    if (pm.last_move == P) m.flags |= NF_DONE;
-  } else {
-    const int color = pm.to_play;
-    label_components(w, V, S, true);
-    group_liberties(w, V, S);
-    int ncap = 0, ko = -1;
-    apply_move_in_scratch(w, V, S, a, color, &ncap, &ko);
-    m.ko = ko;
-    if (pm.to_play == 1) m.caps_b += ncap; else m.caps_w += ncap;
-  }
-  node_init_from_scratch(w, V, S, g, id, m);
-  if (w.leader()) V.child[pi * V.AP + a] = id;
+  if (a == P && pm.last_move == P) m.flags |= NF_DONE;     // pass: done iff the previous move was a pass too
+  GameState& G = V.gs[g];
+  const bool terminal = (m.flags & NF_DONE) || m.n >= V.max_game_length;
+  const bool later = defer && !terminal && G.npend < kMaxPend;
   w.sync();
+  if (w.leader()) {
+    V.meta[node_index(V, g, id)] = m;
+    V.child[pi * V.AP + a] = id;
+    if (later) { V.pend_node[(long)g * kMaxPend + G.npend] = id; G.npend = G.npend + 1; }
+  }
+  w.sync();
+  if (!later) node_expand_child(w, V, S, g, id);
   AGZ_STAMP(w, V, CT_T_CREATE);
 #ifdef AGZ_TIMING_EXPERIMENTS
   w.count(&V.counters[CT_N_CREATE], 1);
 #endif
   return id;
+}
+
+// k_expand: the i-th deferred expansion of game g's select phase
+template <class W>
+AGZ_FN void game_expand(W& w, const View& V, Scratch& S, int g, int i) {
+  if (i >= V.gs[g].npend) return;
+  node_expand_child(w, V, S, g, V.pend_node[(long)g * kMaxPend + i]);
 }
 
 // ------------------------------------------------------------------ PUCT and select_leaf
@@ -463,7 +491,7 @@ AGZ_FN int kth_flag(const int8_t* flag, int n, int k) {
 
 // select_leaf from `from`; the visited nodes are left in S.path[0..len).  Returns the leaf.
 template <class W>
-AGZ_FN int select_leaf(W& w, const View& V, Scratch& S, int g, int from, int* plen_out) {
+AGZ_FN int select_leaf(W& w, const View& V, Scratch& S, int g, int from, int* plen_out, bool defer = false) {
   GameState& G = V.gs[g];
   const int A = V.A, pass = V.P;
   const uint32_t move_key = (uint32_t)V.meta[node_index(V, g, G.root)].n;
@@ -513,7 +541,7 @@ AGZ_FN int select_leaf(W& w, const View& V, Scratch& S, int g, int from, int* pl
       w.sync();
     }
     int nx = V.child[ni * V.AP + pick];
-    if (nx < 0) nx = node_create_child(w, V, S, g, cur, pick);
+    if (nx < 0) nx = node_create_child(w, V, S, g, cur, pick, defer);
     if (nx < 0) break;   // pool exhausted: hand back the current node (flagged in the counters)
     cur = nx;
     depth++;
@@ -891,14 +919,16 @@ AGZ_FN void record_leaf(W& w, const View& V, Scratch& S, int g, int k, int leaf,
 
 // One tree_search! select phase (mcts_play.jl:73-87): up to `par` leaves, `2*par` attempts.
 template <class W>
-AGZ_FN void game_select_phase(W& w, const View& V, Scratch& S, int g, int par) {
+AGZ_FN void game_select_phase(W& w, const View& V, Scratch& S, int g, int par, bool defer = false) {
   GameState& G = V.gs[g];
   int nleaves = 0, failsafe = 0, terminal = 0;
   const float n_before = G.rootN;
+  if (w.leader()) G.npend = 0;
+  w.sync();
   while (nleaves < par && failsafe < 2 * par) {
     failsafe++;
     int plen = 0;
-    const int leaf = select_leaf(w, V, S, g, G.root, &plen);
+    const int leaf = select_leaf(w, V, S, g, G.root, &plen, defer);
     if (node_is_done(V, g, leaf)) {
       load_board(w, V, S, node_index(V, g, leaf));
       const float value = (float)result_of(area_score(w, V, S, G.komi));
@@ -1033,7 +1063,7 @@ AGZ_FN void arena_pre(W& w, const View& V, Scratch& S, int g) {
     if (w.leader()) { G.target = G.rootN + (float)V.R; G.phase = G_SEARCH; }     // :121-126
     w.sync();
   }
-  if (G.phase == G_SEARCH) game_select_phase(w, V, S, g, V.par);
+  if (G.phase == G_SEARCH) game_select_phase(w, V, S, g, V.par, V.defer_expand != 0);
 }
 
 // the active player's budget is spent: :128-146
@@ -1078,6 +1108,7 @@ AGZ_FN void arena_move_phase(W& w, const View& V, Scratch& S, int g) {
 template <class W>
 AGZ_FN void game_pre(W& w, const View& V, Scratch& S, int g) {
   GameState& G = V.gs[g];
+  if (w.leader()) G.npend = 0;       // k_expand looks at every game, whether it selects this step or not
   AGZ_STAMP_BEGIN(w);
   const unsigned long long agz_t_start = agz_t_prev;
   (void)agz_t_start;
@@ -1117,7 +1148,7 @@ AGZ_FN void game_pre(W& w, const View& V, Scratch& S, int g) {
     return;
   }
   if (G.phase == G_SEARCH) {
-    game_select_phase(w, V, S, g, V.par);
+    game_select_phase(w, V, S, g, V.par, V.defer_expand != 0);
 #ifdef AGZ_TIMING_EXPERIMENTS
     const unsigned long long t = w.clock();
     w.count(&V.counters[agz_moved ? CT_T_MOVE_SELECT : CT_T_SELECT], t - agz_t_prev);

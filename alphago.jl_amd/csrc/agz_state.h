@@ -61,8 +61,10 @@ struct GameState {
   int32_t short_first;       // bench stagger: the first search of this game has a shortened budget
   int32_t arena_k;           // arena: games this slot has finished (= local index of the current one)
   int32_t garbage;           // nodes on the deferred-free stack (tail of the slot's free list)
-  int32_t pad;
+  int32_t npend;             // leaves created by this step's select phase whose board update waits for k_expand
 };
+
+constexpr int kMaxPend = 16;    // deferred leaf expansions per game and step (2 x parallel_readouts at most)
 
 enum Counter : int {
   CT_STEPS = 0, CT_POSITIONS, CT_STARTED, CT_FINISHED, CT_EVALS, CT_DUP, CT_TERMINAL, CT_ROOTVISITS,
@@ -86,6 +88,7 @@ struct View {
   uint64_t seed, id_base, id_stride;
   double c_puct, noise_w, alpha, resign_threshold, resign_disable_frac;
   float komi;
+  int32_t defer_expand;   // 1: the select phase only allocates new leaves, k_expand (one wave per leaf) plays the move
   // node pools  [games*cap]
   float* childN;
   float* childW;
@@ -104,6 +107,7 @@ struct View {
   int8_t* leaf_tp;
   int32_t* leaf_plen;
   int32_t* leaf_path;     // [games][par][maxd]
+  int32_t* pend_node;     // [games][kMaxPend]: nodes of GameState::npend
   // live game records [games][mgl]
   int16_t* rec_moves;
   float* rec_pi;          // [games][mgl][A]
