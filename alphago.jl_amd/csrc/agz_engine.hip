@@ -22,6 +22,7 @@ namespace agz {
 // ------------------------------------------------------------------ the wave primitives on gfx950
 
 struct HipWave {
+  static constexpr bool kRegisterRows = true;     // select_leaf_rows (agz_search.h)
   int lane;
   __device__ HipWave() : lane((int)threadIdx.x) {}
   template <class F>
@@ -61,6 +62,8 @@ struct HipWave {
     return v;
   }
   __device__ __forceinline__ bool any(bool v) const { return __any(v) != 0; }
+  __device__ __forceinline__ float shfl(float v, int src) const { return __shfl(v, src, kWave); }
+  __device__ __forceinline__ int shfl(int v, int src) const { return __shfl(v, src, kWave); }
   __device__ __forceinline__ unsigned long long clock() const { return wall_clock64(); }     // 100 MHz
   __device__ __forceinline__ void count_max(unsigned long long* p, unsigned long long v) const {
     if (lane == 0) atomicMax(p, v);

@@ -489,9 +489,124 @@ AGZ_FN int kth_flag(const int8_t* flag, int n, int k) {
   return -1;
 }
 
+// PUCT score from register operands: the arithmetic of action_score, operation for operation
+AGZ_FN double action_score_v(float n, float wv, float p, float to_play, double scale) {
+  const float denom = 1.0f + n;
+  const float q = wv / denom;
+  const float qs = q * to_play;
+  const double u = (scale * (double)p) / (double)denom;
+  return (double)qs + u;
+}
+
+// select_leaf for waves that keep a node's child rows in registers (W::kRegisterRows, the GPU): R = ceil(AP / 64)
+// row elements per lane.  The generic form below walks FOUR dependent global round trips per tree level (meta ->
+// the node's own N in its parent's row -> its child rows for the scores -> the chosen child's id); here everything
+// that depends only on the node id -- meta, N / W / P / child-id rows, the legal words -- is requested at once, the
+// node's own N comes along from the parent's row of the level above, and the chosen child's id and N come out of the
+// registers by shuffle: one round trip per level.  Same arithmetic, same tie-break draws: the tree is bit-identical.
+template <int R, class W>
+AGZ_FN int select_leaf_rows(W& w, const View& V, Scratch& S, int g, int from, int* plen_out, bool defer) {
+  GameState& G = V.gs[g];
+  const int A = V.A, AP = V.AP, pass = V.P;
+  const uint32_t move_key = (uint32_t)V.meta[node_index(V, g, G.root)].n;
+  const uint32_t sel = (uint32_t)G.sel;
+  int cur = from, depth = 0, plen = 0;
+  w.sync();
+  float* np = slotN(V, g, cur);
+  float n_cur = *np;
+  for (;;) {
+    const long ni = node_index(V, g, cur);
+    const NodeMeta m = V.meta[ni];
+    float cn[R], cw[R], cp[R];
+    int cc[R];
+    bool lg[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int a = w.lane + 64 * r;
+      const bool in = a < AP;
+      const long o = ni * AP + (in ? a : 0);
+      cn[r] = V.childN[o];
+      cw[r] = V.childW[o];
+      cp[r] = V.childP[o];
+      cc[r] = in ? V.child[o] : -1;
+      lg[r] = a < A && legal_bit(V, ni, a);
+    }
+    const float n_new = n_cur + 1.0f;
+    w.sync();
+    if (w.leader()) { *np = n_new; if (plen < V.maxd) S.path[plen] = cur; }
+    plen++;
+    w.sync();
+    if (!(m.flags & NF_EXPANDED)) break;
+    auto row_f = [&](const float* v, int a) {              // element a of a row held across the lanes
+      float x = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const float t = w.shfl(v[r], a & 63); if (r == (a >> 6)) x = t; }
+      return x;
+    };
+    int pick;
+    if (m.last_move == pass && row_f(cn, pass) == 0.0f) {
+      pick = pass;    // HACK of mcts.jl:119-126: look at the double pass first
+    } else {
+      const double scale = puct_scale(V, n_new);
+      const float tp = (float)m.to_play;
+      double sc[R];
+      double best = -1.0e300;
+      bool have = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        sc[r] = action_score_v(cn[r], cw[r], cp[r], tp, scale);
+        if (lg[r] && (!have || sc[r] > best)) { best = sc[r]; have = true; }
+      }
+      best = w.reduce_max(have ? best : -1.0e300);
+      int cnt = 0, idx = kIntMax;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int a = w.lane + 64 * r;
+        const bool f = lg[r] && sc[r] == best;
+        if (a < AP) S.flag[a] = f;
+        if (f) { cnt++; idx = a < idx ? a : idx; }
+      }
+      cnt = w.reduce_sum(cnt);
+      idx = w.reduce_min(idx);
+      w.sync();
+      if (cnt > 1) {
+        const uint64_t bits = agz_draw_u64(V.seed, G.game_id, move_key, AGZ_SITE_PUCT_TIE,
+                                           (uint64_t)sel * 1024u + (uint64_t)depth);
+        idx = kth_flag(S.flag, A, (int)agz_index(bits, (uint32_t)cnt));
+      }
+      if (cnt == 0) idx = pass;   // cannot happen: pass is always legal
+      pick = idx;
+      w.sync();
+    }
+    int nx = -1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int t = w.shfl(cc[r], pick & 63); if (r == (pick >> 6)) nx = t; }
+    const float n_next = row_f(cn, pick);
+    if (nx < 0) nx = node_create_child(w, V, S, g, cur, pick, defer);
+    if (nx < 0) break;   // pool exhausted: hand back the current node (flagged in the counters)
+    np = &V.childN[ni * AP + pick];      // the child's own N lives in this row (slotN)
+    n_cur = n_next;
+    cur = nx;
+    depth++;
+  }
+  if (w.leader()) G.sel = (int32_t)(sel + 1);
+  w.sync();
+  *plen_out = plen < V.maxd ? plen : V.maxd;
+  return cur;
+}
+
 // select_leaf from `from`; the visited nodes are left in S.path[0..len).  Returns the leaf.
 template <class W>
 AGZ_FN int select_leaf(W& w, const View& V, Scratch& S, int g, int from, int* plen_out, bool defer = false) {
+  if constexpr (W::kRegisterRows) {
+    switch ((V.AP + 63) >> 6) {
+      case 1: return select_leaf_rows<1>(w, V, S, g, from, plen_out, defer);
+      case 2: return select_leaf_rows<2>(w, V, S, g, from, plen_out, defer);     // 9x9
+      case 3: return select_leaf_rows<3>(w, V, S, g, from, plen_out, defer);     // 13x13
+      case 6: return select_leaf_rows<6>(w, V, S, g, from, plen_out, defer);     // 19x19
+      default: break;
+    }
+  }
   GameState& G = V.gs[g];
   const int A = V.A, pass = V.P;
   const uint32_t move_key = (uint32_t)V.meta[node_index(V, g, G.root)].n;

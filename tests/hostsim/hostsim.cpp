@@ -17,6 +17,7 @@
 namespace {
 
 struct SimWave {
+  static constexpr bool kRegisterRows = false;    // the generic select_leaf (agz_search.h)
   template <class F>
   void for_each(int n, F f) const { for (int i = 0; i < n; ++i) f(i); }
   void sync() const {}
