@@ -140,12 +140,15 @@ class Trainer {
   hipStream_t stream_;
   std::vector<std::unique_ptr<Param>> params_;
   bool have_vel_ = false;
-  DevBuf<float> d_x32_, d_u_, d_o_, d_ga_, d_gb_, d_gc_, d_stats_, d_ones_, d_zero_, d_wd_, d_small_, d_in_;
+  DevBuf<float> d_x32_, d_u_, d_o_, d_ga_, d_gb_, d_gc_, d_stats_, d_ones_, d_zero_, d_wd_, d_small_, d_in_, d_part_, d_wpart_;
   DevBuf<double> d_sums_;
   DevBuf<int> d_cnt_;
 };
 
 // the direct implicit-GEMM 3x3 convolution of agz_nn.hip (y = act(scale * conv + shift (+ res))), cin_pad = 32 or 256
+void launch_conv3x3_direct_taps(const float* x, const float* wt, const float* ones, const float* zeros, const float* shift,
+                                float* y, float* part, const int* d_count, int bcap, int N, int cin_pad, hipStream_t s);
+int conv3x3_direct_blocks(int bcap, int N);
 void launch_conv3x3_direct(const float* x, const float* wt, const float* scale, const float* shift, const float* res,
                            float* y, const int* d_count, int bcap, int N, int relu, int cin_pad, hipStream_t s);
 

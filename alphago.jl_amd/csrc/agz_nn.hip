@@ -32,13 +32,17 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_STRIDE = BK + 4;   // 36 floats: r*36 mod 64 hits 16 distinct 16-B slots for
                                      // the 16 rows of every ds_read_b128 lane group
 
-template <int CIN>
+// TAPSPLIT (the training step's small batches, launch_conv3x3_direct_taps): blockIdx.y = one of the nine taps, the
+// block reduces over that tap's channels only and writes its partial tile to y + blockIdx.y * ystride
+template <int CIN, bool TAPSPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-    const int* __restrict__ d_count, int N, int relu) {
+    const int* __restrict__ d_count, int N, int relu, long ystride = 0) {
   constexpr int NCHUNK = 9 * CIN / BK;
   constexpr int CPT = CIN / BK;  // chunks per tap
+  const int c_begin = TAPSPLIT ? (int)blockIdx.y * CPT : 0, c_end = TAPSPLIT ? c_begin + CPT : NCHUNK;
+  if (TAPSPLIT) y += (long)blockIdx.y * ystride;
   __shared__ __attribute__((aligned(16))) float lds[2][2][BM * LDS_STRIDE];
 
   const int P = N * N;
@@ -102,13 +106,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  AGZ_LOAD_CHUNK(0)
+  AGZ_LOAD_CHUNK(c_begin)
   AGZ_STORE_CHUNK(0)
   __syncthreads();
 
-  for (int c = 0; c < NCHUNK; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < NCHUNK) AGZ_LOAD_CHUNK(c + 1)   // global loads fly under the MFMAs below
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) AGZ_LOAD_CHUNK(c + 1)   // global loads fly under the MFMAs below
     const float* As = &lds[buf][0][(wr * 64 + l31) * LDS_STRIDE + hi * 4];
     const float* Bs = &lds[buf][1][(wc * 64 + l31) * LDS_STRIDE + hi * 4];
 #pragma unroll
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(
       AGZ_MFMA4(x) AGZ_MFMA4(y) AGZ_MFMA4(z) AGZ_MFMA4(w)
 #undef AGZ_MFMA4
     }
-    if (c + 1 < NCHUNK) AGZ_STORE_CHUNK(buf ^ 1)
+    if (c + 1 < c_end) AGZ_STORE_CHUNK(buf ^ 1)
     __syncthreads();
   }
 
@@ -590,6 +594,7 @@ void Net::reserve(int bcap) {
 }
 
 static inline int conv_grid(int bcap, int P) { return ceil_div((long)bcap * P, BM) * (kC / BN); }
+int conv3x3_direct_blocks(int bcap, int N) { return conv_grid(bcap, N * N); }
 
 void launch_conv3x3_direct(const float* x, const float* wt, const float* scale, const float* shift, const float* res,
                            float* y, const int* d_count, int bcap, int N, int relu, int cin_pad, hipStream_t s) {
@@ -598,6 +603,39 @@ void launch_conv3x3_direct(const float* x, const float* wt, const float* scale, 
     hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad>), dim3(grid), dim3(256), 0, s, x, wt, scale, shift, res, y, d_count, N, relu);
   else
     hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, s, x, wt, scale, shift, res, y, d_count, N, relu);
+}
+
+// y[m][n] = sum over the nine tap partials of launch_conv3x3_direct_taps, in tap order, + shift[n]
+__global__ __launch_bounds__(256) void k_sum_taps(const float* __restrict__ part, long stride, const float* __restrict__ shift,
+                                                   float* __restrict__ y, const int* __restrict__ d_count, int P) {
+  const long n4 = (long)(*d_count) * P * (kC / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 s = *reinterpret_cast<const float4*>(part + i * 4);
+#pragma unroll
+    for (int z = 1; z < 9; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(part + z * stride + i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float4 b = *reinterpret_cast<const float4*>(shift + (i * 4) % kC);
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(s.x + b.x, s.y + b.y, s.z + b.z, s.w + b.w);
+  }
+}
+
+// The direct convolution for batches too small to fill the chip with 128-row tiles (the training step at the
+// reference's batch of 32: 42 workgroups): nine times the workgroups, one tap each, partial sums in `part`
+// ([9][bcap N^2][256] floats), then a fixed-order sum + shift.  No scale / residual / ReLU.
+void launch_conv3x3_direct_taps(const float* x, const float* wt, const float* ones, const float* zeros, const float* shift,
+                                float* y, float* part, const int* d_count, int bcap, int N, int cin_pad, hipStream_t s) {
+  const int grid = conv_grid(bcap, N * N);
+  const long stride = (long)bcap * N * N * kC;
+  if (cin_pad == kCinStemPad)
+    hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad, true>), dim3(grid, 9), dim3(256), 0, s, x, wt, ones, zeros,
+                       (const float*)nullptr, part, d_count, N, 0, stride);
+  else
+    hipLaunchKernelGGL((k_conv3x3_mfma<kC, true>), dim3(grid, 9), dim3(256), 0, s, x, wt, ones, zeros, (const float*)nullptr,
+                       part, d_count, N, 0, stride);
+  const int g = (int)std::min<long>(((long)bcap * N * N * (kC / 4) + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_sum_taps, dim3(g), dim3(256), 0, s, (const float*)part, stride, shift, y, d_count, N * N);
 }
 
 void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi, float* d_v) {

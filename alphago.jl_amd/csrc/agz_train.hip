@@ -118,39 +118,85 @@ __global__ void k_take_sums(const double* __restrict__ sums, int C, float* __res
 }
 
 // 3x3 weight gradient in the packed layout of the forward kernel: dWt[co][tap][ci] = sum_m du[m][co] x[m + shift(tap)][ci]
-// grid (256/32, 9, CIN/32), 256 threads: a 32 x 32 (co x ci) tile per block, 4 outputs per thread, rows in chunks of 32
+// as a GEMM whose reduction runs over the rows m, on v_mfma_f32_32x32x2_f32 with both operands straight from global
+// memory: for one row pair an A operand is du[m + k][co0 + lane % 32] and a B operand x[m + k + shift][ci0 + lane % 32]
+// (k = lane / 32) -- two 128-byte runs each.  grid (256/32, 9, CIN/32), 256 threads: a 32 x 32 (co x ci) tile per block,
+// its four waves take the row pairs 4 i + wave and add their partial tiles through LDS in wave order (deterministic).
+// (Round 2's first version was a scalar outer product with double accumulators: 70 % of the training step.  The f32
+// MFMA accumulates B N^2 <= 21 k products per output in f32: relative error ~1e-5 against the 2e-3 bar of
+// tests/test_gpu_train.py.)
+// Large batches split the rows over blockIdx.x / 8 (chunks of `mchunk` rows, a multiple of 8): each split writes its own
+// partial gradient at dwt + split * 256 * 9 * CIN and k_sum_parts adds them in order.
 __global__ __launch_bounds__(256) void k_wgrad3x3(const float* __restrict__ x, const float* __restrict__ du, int B, int N,
-                                                   int CIN, float* __restrict__ dwt) {
-  __shared__ float sd[32][33], sx[32][33];
+                                                   int CIN, float* __restrict__ dwt, int mchunk) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  __shared__ float part[3][16][64];
   const int P = N * N;
-  const long M = (long)B * P;
-  const int co0 = blockIdx.x * 32, tap = blockIdx.y, ci0 = blockIdx.z * 32;
-  const int da = tap % 3 - 1, db = tap / 3 - 1;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty 0..7
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (long m0 = 0; m0 < M; m0 += 32) {
-    for (int r = ty; r < 32; r += 8) {
-      const long m = m0 + r;
-      float dv = 0.f, xv = 0.f;
-      if (m < M) {
-        dv = du[m * kC + co0 + tx];
-        const int p = (int)(m % P), ri = p % N, cj = p / N;
-        if ((unsigned)(ri + da) < (unsigned)N && (unsigned)(cj + db) < (unsigned)N) xv = x[(m + da + N * db) * CIN + ci0 + tx];
-      }
-      sd[r][tx] = dv;
-      sx[r][tx] = xv;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int r = 0; r < 32; ++r) {
-      const float xv = sx[r][tx];
+  const int split = blockIdx.x >> 3;
+  const int mlo = split * mchunk;
+  const int M = min(B * P, mlo + mchunk);                  // < 2^31; this block's rows are [mlo, M)
+  dwt += (size_t)split * kC * 9 * CIN;
+  const int co0 = (blockIdx.x & 7) * 32, tap = blockIdx.y, ci0 = blockIdx.z * 32;
+  const int da = tap % 3 - 1, db = tap / 3 - 1, sh = da + N * db;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  int m = mlo + 2 * wave + kh;                             // this lane's first row; then every eighth
+  int p = m % P, ri = p % N, cj = p / N;
+  const int dr = 8 % N, dc = 8 / N;
+  const float* dcol = du + co0 + l31;
+  const float* xcol = x + ci0 + l31;
+  f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] += (double)sd[r][ty + 8 * q] * (double)xv;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int iters = (M - mlo + 7) / 8;                     // wave-uniform: MFMA needs the whole wave
+  // Branch-free (rows past the end and off-board neighbours load row 0 and are zeroed by a select) and in groups of
+  // 16 row pairs with all 32 loads issued before the first MFMA: left to itself hipcc waits for each pair's loads in
+  // front of its MFMA -- one L2 round trip per 64-cycle MFMA, 0.35 ms per layer at batch 32.
+  constexpr int U = 16;
+  for (int it = 0; it < iters; it += U) {
+    float av[U], bv[U];
+    bool ina[U], okb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ina[u] = m < M;
+      okb[u] = ina[u] && (unsigned)(ri + da) < (unsigned)N && (unsigned)(cj + db) < (unsigned)N;
+      av[u] = dcol[(size_t)(ina[u] ? m : 0) * kC];
+      bv[u] = xcol[(size_t)(okb[u] ? m + sh : 0) * CIN];
+      m += 8;
+      ri += dr;
+      cj += dc;
+      if (ri >= N) { ri -= N; ++cj; }
+      if (cj >= N) cj -= N;
+      if (cj >= N) cj -= N;
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ina[u] ? av[u] : 0.f, okb[u] ? bv[u] : 0.f, acc, 0, 0, 0);
   }
+  // C/D map: col = lane & 31 (ci), row = (e & 3) + 8 (e >> 2) + 4 kh (co)
+  if (wave > 0) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dwt[((long)(co0 + ty + 8 * q) * 9 + tap) * CIN + ci0 + tx] = (float)acc[q];
+    for (int e = 0; e < 16; ++e) part[wave - 1][e][lane] = acc[e];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = ((acc[e] + part[0][e][lane]) + part[1][e][lane]) + part[2][e][lane];
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+      dwt[((long)(co0 + row) * 9 + tap) * CIN + ci0 + l31] = v;
+    }
+  }
+}
+
+// out[i] = part[0][i] + part[1][i] + ... in order (the row splits of k_wgrad3x3)
+__global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ part, int nparts, long stride, float* __restrict__ out,
+                                                    long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float s = part[i];
+    for (int z = 1; z < nparts; ++z) s += part[z * stride + i];
+    out[i] = s;
+  }
 }
 
 // ---- heads, forward (raw, before BatchNorm): cv[m] = x[m] . wv + bv;  cp[m][j] = x[m] . wp[j] + bp[j]
@@ -512,9 +558,18 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
   auto ST = [&](int l) { return stats0 + (size_t)3 * kC * l; };
 
   // ---- forward, training mode
+  // small batches: nine tap-split workgroups per tile and a fixed-order sum (42 workgroups of 128 rows do not fill 256 CUs)
+  const bool taps = conv3x3_direct_blocks(B, N) < 192;
+  d_zero_.ensure(kC);
+  AGZ_HIP(hipMemsetAsync(d_zero_.p, 0, sizeof(float) * kC, s));
+  if (taps) d_part_.ensure((size_t)9 * B * N * N * kC);
   auto conv_bn = [&](int l, const float* in, const float* res) {
-    launch_conv3x3_direct(in, P4(l, 0).theta.p, d_ones_.p, P4(l, 1).theta.p, nullptr, U(l), d_cnt_.p, B, N, 0,
-                          l == 0 ? kCinStemPad : kC, s);
+    if (taps)
+      launch_conv3x3_direct_taps(in, P4(l, 0).theta.p, d_ones_.p, d_zero_.p, P4(l, 1).theta.p, U(l), d_part_.p, d_cnt_.p, B, N,
+                                 l == 0 ? kCinStemPad : kC, s);
+    else
+      launch_conv3x3_direct(in, P4(l, 0).theta.p, d_ones_.p, P4(l, 1).theta.p, nullptr, U(l), d_cnt_.p, B, N, 0,
+                            l == 0 ? kCinStemPad : kC, s);
     zero_sums(kC);
     hipLaunchKernelGGL(k_colsums, dim3(kC / 64, RS), dim3(256), 0, s, (const float*)U(l), M, (int)kC, sums);
     hipLaunchKernelGGL(k_bn_fwd, g1(M * kC), dim3(256), 0, s, (const float*)U(l), M, (int)kC, (const double*)sums,
@@ -602,16 +657,25 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
     hipLaunchKernelGGL(k_colsums, dim3(kC / 64, RS), dim3(256), 0, s, (const float*)du, M, (int)kC, sums);
     hipLaunchKernelGGL(k_take_sums, dim3(1), dim3(256), 0, s, (const double*)sums, (int)kC, P4(l, 1).grad.p);
   };
+  // rows per weight-gradient block: ~2600 (the reference's batch of 32 at 9x9), more blocks for more rows
+  const int wsplit = (int)std::min<long>(16, std::max<long>(1, (M + 2047) / 2592));
+  const int wchunk = (int)(((M + wsplit - 1) / wsplit + 7) / 8 * 8);
+  if (wsplit > 1) d_wpart_.ensure((size_t)wsplit * kC * 9 * kC);
   auto wgrad = [&](int l, const float* in, const float* du) {
     const int cinp = l == 0 ? kCinStemPad : kC;
-    hipLaunchKernelGGL(k_wgrad3x3, dim3(kC / 32, 9, cinp / 32), dim3(256), 0, s, in, du, B, N, cinp, P4(l, 0).grad.p);
+    const long n = (long)kC * 9 * cinp;
+    if (wsplit == 1) {
+      hipLaunchKernelGGL(k_wgrad3x3, dim3(kC / 32, 9, cinp / 32), dim3(256), 0, s, in, du, B, N, cinp, P4(l, 0).grad.p, wchunk);
+    } else {
+      hipLaunchKernelGGL(k_wgrad3x3, dim3(kC / 32 * wsplit, 9, cinp / 32), dim3(256), 0, s, in, du, B, N, cinp, d_wpart_.p, wchunk);
+      hipLaunchKernelGGL(k_sum_parts, g1(n), dim3(256), 0, s, (const float*)d_wpart_.p, wsplit, n, P4(l, 0).grad.p, n);
+    }
   };
   // dx = conv(du) with Wd[ci][tap'][co] = Wt[co][8 - tap'][ci]
-  d_zero_.ensure(kC);
-  AGZ_HIP(hipMemsetAsync(d_zero_.p, 0, sizeof(float) * kC, s));
   auto dgrad = [&](int l, const float* du, float* dx) {
     hipLaunchKernelGGL(k_make_wd, g1((long)kC * 9 * kC), dim3(256), 0, s, (const float*)P4(l, 0).theta.p, d_wd_.p);
-    launch_conv3x3_direct(du, d_wd_.p, d_ones_.p, d_zero_.p, nullptr, dx, d_cnt_.p, B, N, 0, kC, s);
+    if (taps) launch_conv3x3_direct_taps(du, d_wd_.p, d_ones_.p, d_zero_.p, d_zero_.p, dx, d_part_.p, d_cnt_.p, B, N, kC, s);
+    else launch_conv3x3_direct(du, d_wd_.p, d_ones_.p, d_zero_.p, nullptr, dx, d_cnt_.p, B, N, 0, kC, s);
   };
   float *du = d_gb_.p, *dsc = d_gc_.p;
   for (int blk = t - 1; blk >= 0; --blk) {

@@ -11,7 +11,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import alphago_jl_amd as ag  # noqa: E402
 
-for N, tower, B in ((9, 10, 32), (19, 20, 32), (9, 10, 256)):
+CONFIGS = ((9, 10, 32), (19, 20, 32), (9, 10, 256))
+if len(sys.argv) > 1:                      # train_micro.py <index>: one configuration only (for rocprofv3 --stats)
+    CONFIGS = (CONFIGS[int(sys.argv[1])],)
+for N, tower, B in CONFIGS:
     eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
     eng.init_synthetic(0)
     rng = np.random.RandomState(0)
