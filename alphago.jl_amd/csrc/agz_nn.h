@@ -143,6 +143,8 @@ class Trainer {
   DevBuf<float> d_x32_, d_u_, d_o_, d_ga_, d_gb_, d_gc_, d_stats_, d_ones_, d_zero_, d_wd_, d_small_, d_in_, d_part_, d_wpart_;
   DevBuf<double> d_sums_;
   DevBuf<int> d_cnt_;
+  DevBuf<unsigned char> d_opta_, d_optw_;     // k_momentum_all's array table and work list (built with the parameter set)
+  int n_optw_ = 0;
 };
 
 // the direct implicit-GEMM 3x3 convolution of agz_nn.hip (y = act(scale * conv + shift (+ res))), cin_pad = 32 or 256

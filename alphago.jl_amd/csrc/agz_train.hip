@@ -328,24 +328,32 @@ __global__ void k_head1x1_dgrad(const float* __restrict__ dcv, const float* __re
   const int c = (int)(i % kC);
   dx[i] = dcv[m] * wv[c] + dcp[m * 2] * wp[c] + dcp[m * 2 + 1] * wp[kC + c];
 }
-// dwv[c] = sum_m dcv[m] x[m][c]; dwp[j][c]; dbv, dbp: one thread per channel (M <= a few 10^4)
-__global__ void k_head1x1_wgrad(const float* __restrict__ x, const float* __restrict__ dcv, const float* __restrict__ dcp,
-                                long M, float* __restrict__ dwv, float* __restrict__ dwp, float* __restrict__ dbv,
-                                float* __restrict__ dbp) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= kC) return;
+// dwv[c] = sum_m dcv[m] x[m][c]; dwp[j][c]; dbv, dbp.  One thread per channel, the rows in gridDim.x slices whose double
+// partial sums meet in sums[0..3 kC + 3) (zeroed by the caller; one block over all rows was 10 % of a batch-32 step)
+__global__ __launch_bounds__(256) void k_head1x1_wgrad(const float* __restrict__ x, const float* __restrict__ dcv,
+                                                        const float* __restrict__ dcp, long M, double* __restrict__ sums) {
+  const int c = threadIdx.x;
+  const long per = (M + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < M ? lo + per : M;
   double sv = 0.0, s0 = 0.0, s1 = 0.0, bv = 0.0, b0 = 0.0, b1 = 0.0;
-  for (long m = 0; m < M; ++m) {
+  for (long m = lo; m < hi; ++m) {
     const double xv = x[m * kC + c];
     sv += xv * dcv[m];
     s0 += xv * dcp[m * 2];
     s1 += xv * dcp[m * 2 + 1];
     if (c == 0) { bv += dcv[m]; b0 += dcp[m * 2]; b1 += dcp[m * 2 + 1]; }
   }
-  dwv[c] = (float)sv;
-  dwp[c] = (float)s0;
-  dwp[kC + c] = (float)s1;
-  if (c == 0) { dbv[0] = (float)bv; dbp[0] = (float)b0; dbp[1] = (float)b1; }
+  atomicAdd(&sums[c], sv);
+  atomicAdd(&sums[kC + c], s0);
+  atomicAdd(&sums[2 * kC + c], s1);
+  if (c == 0) { atomicAdd(&sums[3 * kC], bv); atomicAdd(&sums[3 * kC + 1], b0); atomicAdd(&sums[3 * kC + 2], b1); }
+}
+__global__ __launch_bounds__(256) void k_head1x1_wgrad_take(const double* __restrict__ sums, float* __restrict__ dwv,
+                                                             float* __restrict__ dwp, float* __restrict__ dbv, float* __restrict__ dbp) {
+  const int c = threadIdx.x;
+  dwv[c] = (float)sums[c];
+  dwp[c] = (float)sums[kC + c];
+  dwp[kC + c] = (float)sums[2 * kC + c];
+  if (c == 0) { dbv[0] = (float)sums[3 * kC]; dbp[0] = (float)sums[3 * kC + 1]; dbp[1] = (float)sums[3 * kC + 2]; }
 }
 
 __global__ void k_add(float* __restrict__ a, const float* __restrict__ b, long n) {
@@ -353,26 +361,30 @@ __global__ void k_add(float* __restrict__ a, const float* __restrict__ b, long n
   if (i < n) a[i] += b[i];
 }
 
-// sum theta^2 (loss_reg) -> losses[2]
-__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ t, long n, double* __restrict__ out) {
+// Momentum (Flux): g = grad + 2 * 1e-4 * theta; vel = rho vel - eta g; theta += vel -- every parameter array in one
+// launch: blockIdx.x -> (array, chunk of kOptChunk elements) through a work list built once per parameter set; sum theta^2 of the values BEFORE the update (loss_reg) goes to losses[2] on the way
+struct OptArray { float* theta; const float* grad; float* vel; long n; };
+struct OptWork { int array; int chunk; };
+constexpr int kOptChunk = 16384;
+__global__ __launch_bounds__(256) void k_momentum_all(const OptArray* __restrict__ arrays, const OptWork* __restrict__ work,
+                                                       float eta, float rho, double* __restrict__ sumsq) {
   __shared__ double red[256];
+  const OptWork wk = work[blockIdx.x];
+  const OptArray a = arrays[wk.array];
+  const long lo = (long)wk.chunk * kOptChunk, hi = lo + kOptChunk < a.n ? lo + kOptChunk : a.n;
   double s = 0.0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += (double)t[i] * (double)t[i];
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float th = a.theta[i];
+    s += (double)th * (double)th;
+    const float g = a.grad[i] + 2.f * kRegW * th;
+    const float v = rho * a.vel[i] - eta * g;
+    a.vel[i] = v;
+    a.theta[i] = th + v;
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) atomicAdd(out, red[0]);
-}
-
-// Momentum (Flux): g = grad + 2 * 1e-4 * theta; vel = rho vel - eta g; theta += vel
-__global__ void k_momentum(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ vel, long n, float eta,
-                           float rho) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float g = grad[i] + 2.f * kRegW * theta[i];
-  const float v = rho * vel[i] - eta * g;
-  vel[i] = v;
-  theta[i] += v;
+  if (threadIdx.x == 0) atomicAdd(sumsq, red[0]);
 }
 
 // input-gradient weights of a 256 -> 256 layer: Wd[ci][tap'][co] = Wt[co][8 - tap'][ci]  (shift(8 - tap) = -shift(tap))
@@ -511,7 +523,7 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
   d_gb_.ensure(act);
   d_gc_.ensure(act);
   d_stats_.ensure((size_t)3 * kC * L + 16);
-  d_sums_.ensure((size_t)2 * kC + 8);
+  d_sums_.ensure((size_t)4 * kC + 8);
   d_ones_.ensure(kC);
   d_wd_.ensure((size_t)kC * 9 * kC);
   d_small_.ensure((size_t)M * 9 + (size_t)B * (A * 3 + 256 * 2 + 8) + 64);
@@ -545,7 +557,7 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
   float* dlogit = pout + (size_t)B * A;      // [B][A]
   float* dsv = dlogit + (size_t)B * A;       // [B]
   float* dd1 = dsv + B;                      // [B][256]
-  double* d_losses = reinterpret_cast<double*>(d_sums_.p) + 2 * kC;       // [4] behind the column sums
+  double* d_losses = reinterpret_cast<double*>(d_sums_.p) + 4 * kC;       // [4] behind the column sums
   double* sums = reinterpret_cast<double*>(d_sums_.p);
   auto zero_sums = [&](int C) { AGZ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s)); };
   AGZ_HIP(hipMemsetAsync(d_losses, 0, sizeof(double) * 4, s));
@@ -607,8 +619,6 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
                      (const float*)Bf.theta.p, B, 2 * P, A, 0, logits);
   hipLaunchKernelGGL(k_outputs, dim3(B), dim3(256), 0, s, (const float*)logits, (const float*)vout, (const float*)d_pi,
                      (const float*)d_z, B, A, pout, dlogit, dsv, d_losses);
-  for (auto& p : params_)
-    hipLaunchKernelGGL(k_sumsq, dim3(64), dim3(256), 0, s, (const float*)p->theta.p, (long)p->n, d_losses + 2);
 
   // ---- backward: heads
   hipLaunchKernelGGL(k_dense_wgrad, g1((long)A * 2 * P), dim3(256), 0, s, (const float*)hp, 2, P, (const float*)dlogit, B, 2 * P,
@@ -638,8 +648,10 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
   hipLaunchKernelGGL(k_bn_bwd_apply, g1(M * 2), dim3(256), 0, s, (const float*)dhp, (const float*)hp, (const float*)cp,
                      (const float*)st_p, (const float*)Gp.theta.p, (const double*)sums, M, 2, 1, dcp, (float*)nullptr, Gp.grad.p,
                      BEp.grad.p);
-  hipLaunchKernelGGL(k_head1x1_wgrad, dim3(1), dim3(256), 0, s, xL, (const float*)dcv, (const float*)dcp, M, Wv.grad.p,
-                     Wp.grad.p, Bv.grad.p, Bp.grad.p);
+  AGZ_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (3 * kC + 3), s));
+  hipLaunchKernelGGL(k_head1x1_wgrad, dim3(RS), dim3(256), 0, s, xL, (const float*)dcv, (const float*)dcp, M, sums);
+  hipLaunchKernelGGL(k_head1x1_wgrad_take, dim3(1), dim3(256), 0, s, (const double*)sums, Wv.grad.p, Wp.grad.p, Bv.grad.p,
+                     Bp.grad.p);
   float* g = d_ga_.p;      // gradient wrt the current block output
   hipLaunchKernelGGL(k_head1x1_dgrad, g1(M * kC), dim3(256), 0, s, (const float*)dcv, (const float*)dcp, (const float*)Wv.theta.p,
                      (const float*)Wp.theta.p, M, g);
@@ -691,14 +703,28 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
   bn_back(0, g, du, nullptr);
   wgrad(0, d_x32_.p, du);
 
-  // ---- read the losses (as they were before the update), then the optimiser
+  // ---- the optimiser (one launch over every array; it also sums theta^2 of the values before the update), then the losses
+  if (d_optw_.n == 0) {
+    std::vector<OptArray> arr;
+    std::vector<OptWork> work;
+    for (auto& p : params_) {
+      for (long c = 0; c * kOptChunk < (long)p->n; ++c) work.push_back(OptWork{(int)arr.size(), (int)c});
+      arr.push_back(OptArray{p->theta.p, p->grad.p, p->vel.p, (long)p->n});
+    }
+    d_opta_.alloc(arr.size() * sizeof(OptArray));
+    d_optw_.alloc(work.size() * sizeof(OptWork));
+    AGZ_HIP(hipMemcpyAsync(d_opta_.p, arr.data(), arr.size() * sizeof(OptArray), hipMemcpyHostToDevice, s));
+    AGZ_HIP(hipMemcpyAsync(d_optw_.p, work.data(), work.size() * sizeof(OptWork), hipMemcpyHostToDevice, s));
+    AGZ_HIP(hipStreamSynchronize(s));
+    n_optw_ = (int)work.size();
+  }
+  hipLaunchKernelGGL(k_momentum_all, dim3(n_optw_), dim3(256), 0, s, reinterpret_cast<const OptArray*>(d_opta_.p),
+                     reinterpret_cast<const OptWork*>(d_optw_.p), eta, rho, d_losses + 2);
   double hl[4];
   AGZ_HIP(hipMemcpyAsync(hl, d_losses, sizeof(hl), hipMemcpyDeviceToHost, s));
   // batch statistics for the running-statistics update
   std::vector<float> hst((size_t)3 * kC * L + 9);
   AGZ_HIP(hipMemcpyAsync(hst.data(), d_stats_.p, sizeof(float) * hst.size(), hipMemcpyDeviceToHost, s));
-  for (auto& p : params_)
-    hipLaunchKernelGGL(k_momentum, g1((long)p->n), dim3(256), 0, s, p->theta.p, (const float*)p->grad.p, p->vel.p, (long)p->n, eta, rho);
   AGZ_HIP(hipGetLastError());
   AGZ_HIP(hipStreamSynchronize(s));
   if (losses_out) {
