@@ -37,17 +37,18 @@ def f_eval(N, t):
     return 2.0 * P * (9 * 17 * 256 + t * 2 * 9 * 256 * 256) + 2.0 * P * 256 * 3 + 2.0 * (2 * P * (P + 1) + P * 256 + 256)
 
 
-def pmc_traffic(rows_per_launch):
+def pmc_traffic(rows_per_launch, precision="f32"):
     """HBM bytes per tower-conv launch, from the committed rocprofv3 --pmc passes.
 
     Hardware counters cannot be read from inside this process; FETCH_SIZE and WRITE_SIZE were
     collected in two separate `rocprofv3 --pmc` runs of tools/nn_micro.py (same kernels, full
     8192-position batch) and summarised into profiles/pmc_traffic.json as bytes per board-point row.
     Scaled here by the average rows per launch of THIS run.  None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    name = "pmc_traffic.json" if precision == "f32" else f"r02_pmc_traffic_{precision}.json"
+    path = os.path.join(ROOT, "profiles", name)
     try:
         d = json.load(open(path))
-        return d["bytes_per_row"] * rows_per_launch, f"profiles/pmc_traffic.json ({d['source']})"
+        return d["bytes_per_row"] * rows_per_launch, f"profiles/{name} ({d['source']})"
     except Exception:
         return None, None
 
@@ -291,7 +292,7 @@ def main():
         f16, f32s = args.precision == "f16", args.precision == "f32s"
         wino_ratio = 1.0 if f16 else 25.0 * T * T / (9.0 * N * N)   # executed / algorithmic multiplies of F(3x3,3x3)
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_src = (None, None) if (f16 or N != 9) else pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256))
+        traffic, traffic_src = (None, None) if N != 9 else pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), args.precision)
         # The roofline object.  `achieved`/`frac` are what the MFMA pipe EXECUTES: Winograd F(3x3,3x3) needs 25
         # multiplies per 3x3 output tile and (cin, cout) pair instead of 81, all of them still f32, so the
         # honest fraction of the f32 MFMA peak is executed flops / time / peak (<= 1).  The rate in terms of the
@@ -325,7 +326,7 @@ def main():
                     "stream around every tower-conv launch of the timed region); achieved_algorithmic = 2*rows*9*256*256 "
                     "per launch / the same time",
             "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": 2560.0 * conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256),
+            "algorithmic_bytes_per_launch": (1280.0 if f16 else 2560.0) * conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256),
             "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
             "executed_flop_per_launch_avg": conv_flop * wino_ratio / max(conv_n, 1),
             "algorithmic_flop_per_launch_avg": conv_flop / max(conv_n, 1),
