@@ -75,8 +75,9 @@ __device__ __forceinline__ void glds16hs(const void* gbase_uniform, unsigned lan
 //   * workgroups are persistent (one per CU, tiles blockIdx.x, +gridDim.x, ...): the next tile's first slab and
 //     weight fragments are in flight while the epilogue runs; residual pieces are fetched two passes ahead, the
 //     first two during the last channel chunk.  The epilogue of a half-in / half-out layer only computes: its
-//     results stay in a wave-private LDS image (7 passes x 4 KB per wave, dense 128-byte rows, 16-byte pieces
-//     swizzled by row) and leave for HBM one 1 KB piece every fourth k-step of the NEXT tile's loop.  (224 rows,
+//     results stay in an LDS image (7 passes x 32 rows x 512 bytes, 16-byte pieces swizzled by row; a wave computes
+//     into its own 128-byte slice of every row) and leave for HBM two whole rows (1 KB) every fourth k-step of the NEXT
+//     tile's loop.  (224 rows,
 //     not 256: the image of an eighth pass does not fit beside the slabs.)  The last tile's image is flushed at
 //     the end.  Rows past the batch are stored too: the half activation buffers are padded by one tile
 //     (Net::reserve).  The f32-residual layer (first block) and the f32-output layer (last) keep a direct
@@ -225,16 +226,23 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
     Bf[slot][1] = *reinterpret_cast<const h8*>(p + 1024 + wlane);
   };
 
-  // result image of this wave; a lane's piece i (0..3) of a pass is row (lane >> 3) + 8 i, 16-byte column lane & 7
-  char* outw = sm + W2_OFF_OUT * 2 + wave * (W2_RB * 4096);
-  int tl[4];
+  // Result image of the workgroup: [pass 7][32 rows][512 B], a row's thirty-two 16-byte pieces swizzled by the row
+  // (piece q of row r sits at q ^ r).  A wave computes into its own 128-byte slice of every row (pieces wave*8 ..+7);
+  // the image LEAVES in whole rows -- a store instruction is two consecutive 512-byte rows = 1 KB contiguous in HBM,
+  // whichever wave issues it.  (Against wave-private images that leave as 128-byte row segments: the same time within
+  // 0.3 % in an A/B on one box -- the clock the stores cost does not depend on their shape.)
+  char* outw = sm + W2_OFF_OUT * 2;
+  int tr[4];                                               // residual in: this lane's piece i of a pass = row (lane >> 3) + 8 i, column lane & 7 of the slice
+  int tl[4];                                               // image out: row pair wave + 4 i of a pass, lane = (row of the pair, piece)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (lane >> 3) + 8 * i;
-    tl[i] = row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    tr[i] = row * 512 + (((wave * 8 + (lane & 7)) ^ row) << 4);
+    const int orow = 2 * (wave + 4 * i) + (lane >> 5);
+    tl[i] = orow * 512 + (((lane & 31) ^ orow) << 4);
   }
-  const unsigned tg = (unsigned)((lane >> 3) * (kC * 2) + (lane & 7) * 16 + wave * 128);   // + i * 4096 + pass * 16384 + tile base
-  const int lx = (l31 * 128 + 8 * hi) | (((l31 >> 1) & 7) << 4);                             // lane's 8-byte group: lx ^ (piece << 4)
+  const unsigned tg = (unsigned)((2 * wave + (lane >> 5)) * (kC * 2) + (lane & 31) * 16);     // + i * 4096 + pass * 16384 + tile base
+  const int lx = l31 * 512 + 8 * hi + (((wave * 8) ^ l31) << 4);                              // lane's 8-byte group: lx ^ (piece << 4), piece 0..7 of the slice
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   u4 treg = {0, 0, 0, 0};
   char* yprev = nullptr;                                  // tile whose image is leaving: base of its rows in y
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
         }
         // chunk cc sends pass cc of the previous tile's image on its way: piece i / 4, read one k-step before it is stored
         if (TRICKLE && !last && !(DBG & 33) && mi == 12) {
-          if constexpr (i % 4 == 2) treg = *reinterpret_cast<const u4*>(outw + cc * 4096 + tl[i / 4]);
+          if constexpr (i % 4 == 2) treg = *reinterpret_cast<const u4*>(outw + cc * 16384 + tl[i / 4]);
           if constexpr (i % 4 == 3) *reinterpret_cast<u4*>(yprev + (size_t)cc * (32 * kC * 2) + (i / 4) * 4096 + tg) = treg;
         }
         if (last && RES != 0 && !(DBG & 1) && mi == 2 * RB - 2) {  // the first passes' residual, spread over the last chunk
@@ -370,11 +378,11 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
       // compute only: results (and before them the residual) live in this wave's image, the stores ride on the next tile
       auto pass = [&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
-        char* img = outw + r * 4096;
+        char* img = outw + r * 16384;
         if (RES != 0) {
           static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            *reinterpret_cast<uint4*>(img + tl[i]) = rr(std::integral_constant<int, (r % NRR) * 4 + i>{});
+            *reinterpret_cast<uint4*>(img + tr[i]) = rr(std::integral_constant<int, (r % NRR) * 4 + i>{});
           });
           if constexpr (r + NRR < W2_RB) load_res(std::integral_constant<int, r + NRR>{});
         }
@@ -400,6 +408,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
       };
       static_for<0, W2_RB>(pass);
       yprev = reinterpret_cast<char*>(y) + (size_t)m0 * (kC * 2);
+      __syncthreads();                                      // the image is complete: any wave may send any row
     } else {
       // direct: residual and result cross a wave-private LDS tile each, so that HBM sees 16-byte pieces of whole rows
       char* Tin = sm + W2_OFF_OUT * 2 + wave * TINB;
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
     for (int r = 0; r < W2_RB; ++r)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<u4*>(yprev + (size_t)r * (32 * kC * 2) + i * 4096 + tg) = *reinterpret_cast<const u4*>(outw + r * 4096 + tl[i]);
+        *reinterpret_cast<u4*>(yprev + (size_t)r * (32 * kC * 2) + i * 4096 + tg) = *reinterpret_cast<const u4*>(outw + r * 16384 + tl[i]);
   }
 }
 

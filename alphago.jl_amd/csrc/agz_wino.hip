@@ -300,6 +300,13 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
   };
 
+  // the first two stages are on their way before anything else: the point table and the 400 accumulator zeros below
+  // (~1 us per workgroup, 18 rounds per layer) run under their latency
+#pragma unroll
+  for (int j = 0; j < 13; ++j) dma(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < 13; ++j) dma(1, 1, j);
+
   for (int idx = tid; idx < WT * 9; idx += 256) {     // (published by the barrier in front of the first operand reads)
     const int row = idx & (WT - 1), k = idx >> 6;       // X = k * 64 + row
     const long tile = (long)tb * RPB + row;
@@ -369,10 +376,6 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     }
   };
 
-#pragma unroll
-  for (int j = 0; j < 13; ++j) dma(0, 0, j);
-#pragma unroll
-  for (int j = 0; j < 13; ++j) dma(1, 1, j);
   asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
   __syncthreads();
 #pragma unroll
