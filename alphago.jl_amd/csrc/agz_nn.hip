@@ -648,7 +648,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
   // The stem goes through the Winograd GEMM too when the tower does (8 K-loop stages for its 17 -> 32 padded input
   // planes instead of a direct convolution over K = 9 x 32): its epilogue then also emits the first tower layer's V,
   // and the one k_wino_in per forward shrinks to the 32-channel feature planes.
-  const bool stem_wino = precision_ != 1 && winograd_ && tower_ > 0;
+  const bool stem_wino = winograd_ && tower_ > 0;
   if (!stem_wino)
     hipLaunchKernelGGL((k_conv3x3_mfma<kCinStemPad>), dim3(grid), dim3(256), 0, stream_, d_x32, d_wstem_.p,
                        d_scale_.p, d_shift_.p, (const float*)nullptr, a, d_count, N_, 1);
@@ -669,6 +669,11 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
     // the heads; the residual of block 0 is the unrounded f32 stem output
     const size_t iper = conv16_image_halves();
     uint16_t *cur = d_hb_.p, *nxt = d_ha_.p;
+    if (stem_wino) {                                 // the f32 stem as an 8-stage Winograd GEMM (y only)
+      launch_wino_in(d_x32, d_vimg_.p, d_count, bcap, N_, false, stream_, kWinoStemStages);
+      launch_wino_gemm(d_vimg_.p, d_ustem_.p, d_scale_.p, d_shift_.p, nullptr, a, nullptr, d_count, bcap, N_, 1, false, stream_,
+                       kWinoStemStages);
+    }
     launch_f32_to_f16(a, cur, d_count, bcap, N_, stream_);
     for (int blk = 0; blk < tower_; ++blk) {
       const int l1 = 2 * blk, l2 = 2 * blk + 1;
