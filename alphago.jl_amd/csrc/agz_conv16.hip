@@ -77,9 +77,8 @@ __device__ __forceinline__ void glds16hs(const void* gbase_uniform, unsigned lan
 //     first two during the last channel chunk.  The epilogue of a half-in / half-out layer only computes: its
 //     results stay in an LDS image (7 passes x 32 rows x 512 bytes, 16-byte pieces swizzled by row; a wave computes
 //     into its own 128-byte slice of every row) and leave for HBM two whole rows (1 KB) every fourth k-step of the NEXT
-//     tile's loop.  (224 rows,
-//     not 256: the image of an eighth pass does not fit beside the slabs.)  The last tile's image is flushed at
-//     the end.  Rows past the batch are stored too: the half activation buffers are padded by one tile
+//     tile's loop.  (224 rows, not 256: the image of an eighth pass does not fit beside the slabs.)  The last tile's
+//     image is flushed at the end.  Rows past the batch are stored too: the half activation buffers are padded by one tile
 //     (Net::reserve).  The f32-residual layer (first block) and the f32-output layer (last) keep a direct
 //     epilogue through two small tiles per wave: two layers of twenty.
 // What the timing variants and the counters say (tools/c16_x.sh, tools/c16_pmc.sh; 8192 positions of 9x9):
@@ -91,7 +90,7 @@ __device__ __forceinline__ void glds16hs(const void* gbase_uniform, unsigned lan
 //   power-limited here (MI355X_MICROARCH.md, DVFS), and every HBM byte is paid in clock.  Everything tried against a
 //   supposed "store tail" therefore measured nothing: staggered workgroup starts, a 17-deep weight ring, results
 //   trickled through the LDS image instead of stored in a burst, 128-row tiles with two workgroups per CU (0.659 vs
-//   0.665 ms), non-temporal stores.  (An intermediate form with the weights in LDS -- 128 x 128 wave tiles, 48 KB
+//   0.665 ms), non-temporal stores, whole rows instead of 128-byte segments per store.  (An intermediate form with the weights in LDS -- 128 x 128 wave tiles, 48 KB
 //   weight groups by LDS-DMA -- ran its loop in 0.48 ms and 0.38 ms with the DMA compiled out: the DMA writes compete
 //   with the operand reads for the LDS port.)  Same lesson from the LDS side: the lanes that read the shared row of
 //   zeros make nearly every slab read a 2-way bank conflict (SQ_LDS_BANK_CONFLICT 0.36 of the LDS cycles); giving each
