@@ -436,14 +436,13 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   // img (layout above).  Phases, each with every memory operation of the phase in flight at once -- a lone wave
   // per SIMD has nobody to hide a load -> use round trip behind:
   //   0   residual -> img by LDS-DMA (144 KB in 144 instructions), in flight during the register work of phase 1
-  //   1   inverse transform A^T M A + BatchNorm affine in registers, then img = img (the residual) + value
-  //   1b  img -> ReLU -> y and back to img: 256-byte runs per output point, 16 B per lane; skipped when there is
-  //       neither a residual nor a y to write (conv1 of a block: ReLU happens in phase 1)
+  //   1   inverse transform A^T M A + BatchNorm affine in registers, then img = ReLU(img (the residual) + value)
+  //   1b  img -> y: 256-byte runs per output point, 16 B per lane; only where y is wanted (MODE & 1)
   //   2   next layer's input transform V = B^T d B from img -> HBM stage images   (MODE & 2)
   __syncthreads();
   float* img = lds;
   static_assert(IMG_FLOATS <= 3 * STAGE, "tile image exceeds the stage buffers");
-  const bool pass1b = (MODE & 1) || res != nullptr;
+  const bool pass1b = (MODE & 1) != 0;
   if (res) {
     // instruction i fills points 4i .. 4i+3: lane = (point, unit u) fetches channel group u ^ (X & 15)
     for (int i = wave; i < WT * 9 / 4; i += 4) {
@@ -457,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     // phase 1.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     const int col = wn * 32 + l31;
     const float sc = scale[cb * WC + col], sh = shift[cb * WC + col];
-    const bool relu_now = relu && !pass1b;
+    const bool relu_now = relu != 0;       // ReLU here, on the way into the image: phase 1b only has to copy
     // whole 16-register tuples at a time (element e of a tuple = tile row e of the C/D map): extracting single
     // elements of AGPR-resident tuples made hipcc copy entire tuples back and forth (330 instructions per e)
     f32x16 o[9];
@@ -529,16 +528,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 #pragma unroll
       for (int j = 0; j < 12; ++j) v[j] = ip0[256 * (i0 + j)];
 #pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        if (relu) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[j][c] = fmaxf(v[j][c], 0.f);
-        }
+      for (int j = 0; j < 12; ++j)
         if ((MODE & 1) && offs[i0 + j] >= 0) *reinterpret_cast<f32x4*>(y + offs[i0 + j] + cg4) = v[j];
-        if (MODE & 2) ip0[256 * (i0 + j)] = v[j];      // (dead points: never read)
-      }
     }
-    if (MODE & 2) __syncthreads();
   }
   if (!(MODE & 2) || X == 2) return;
 
