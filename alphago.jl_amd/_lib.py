@@ -159,6 +159,7 @@ def load():
         "agz_comm_destroy": (None, [E]),
         "agz_allgather_records": (i32, [E, E, P(i64)]),
         "agz_broadcast_weights": (i32, [E, E, i32, P(i64)]),
+        "agz_gather_plan": (i32, [P(i64), i32, P(i64), P(i64)]),
         "agz_abi_layout": (i32, [C.c_char_p, i32p, i32]),
         "agz_tree_init": (i32, [E, i32, i8p, P(PositionInfo), i8p]),
         "agz_tree_root": (i32, [E, i32, i32p]),

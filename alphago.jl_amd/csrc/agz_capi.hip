@@ -295,6 +295,16 @@ agz_status agz_allgather_records(agz_engine* e, agz_comm* comm, int64_t* added_o
     if (added_out) *added_out = n;
   });
 }
+agz_status agz_gather_plan(const int64_t* counts, int32_t world, int64_t* chunk_stride_out, int64_t* total_records_out) {
+  if (!chunk_stride_out) return AGZ_BAD_ARGUMENT;
+  try {
+    *chunk_stride_out = agz::gather_plan(counts, world, total_records_out);
+    return AGZ_OK;
+  } catch (const agz::Error& x) {
+    g_create_error = x.what();
+    return x.status;
+  }
+}
 agz_status agz_broadcast_weights(agz_engine* e, agz_comm* comm, int32_t root, int64_t* nfloats_out) {
   return guard(e, [&](agz::Engine& E) {
     const int64_t n = agz::comm_broadcast_weights(E, reinterpret_cast<agz::Comm*>(comm), root);

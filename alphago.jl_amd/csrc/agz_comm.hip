@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -40,13 +41,21 @@ static Rccl& rccl() {
   static Rccl R;
   static std::once_flag once;
   std::call_once(once, [] {
+    // AGZ_RCCL_SONAME overrides the search (a site with its own RCCL build; the CPU suite uses it to force the
+    // not-found path, which must be an AGZ_RCCL_ERROR status and never a crash)
+    const char* forced = getenv("AGZ_RCCL_SONAME");
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why = "?";
     for (const char* n : names) {
+      if (forced) n = forced;
       R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (R.lib) break;
+      const char* e = dlerror();          // (dlerror() clears the message: read it exactly once per failure)
+      if (e) why = e;
+      if (forced) break;
     }
     if (!R.lib) {
-      R.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "?");
+      R.error = std::string(forced ? forced : "librccl.so.1") + " not found: " + why;
       return;
     }
     auto sym = [&](const char* s) {
@@ -110,55 +119,73 @@ void comm_destroy(Comm* c) {
   delete c;
 }
 
-// records of every rank -> this rank's replay arena, rank order; returns the number of games added
+// The host logic between the two collectives, independent of what carries the bytes (RCCL here, the host's own
+// library through agz_gather_plan + agz_replay_ingest_gathered): counts = {records, bytes} per rank as gathered.
+// A rank that failed BEFORE the exchange still takes part in the count collective and announces {-1, its status},
+// so that every rank fails the call together instead of hanging in the payload collective.
+int64_t gather_plan(const int64_t* counts, int world, int64_t* total_records) {
+  AGZ_REQUIRE(counts != nullptr && world >= 1, AGZ_BAD_ARGUMENT, "gather plan over %d ranks", world);
+  int64_t mx = 0, total = 0;
+  for (int r = 0; r < world; ++r) {
+    const int64_t n = counts[2 * r], b = counts[2 * r + 1];
+    AGZ_REQUIRE(n != -1, AGZ_RCCL_ERROR, "rank %d failed before the exchange (status %lld): no rank ingests anything", r,
+                (long long)b);
+    // a record is at least a header and at most header + max_game_length moves: bytes and records must be consistent
+    AGZ_REQUIRE(n >= 0 && b >= 0 && b % 8 == 0 && (n == 0) == (b == 0) && b >= n * (int64_t)sizeof(agz_game_header),
+                AGZ_RCCL_ERROR, "rank %d announced %lld records in %lld bytes", r, (long long)n, (long long)b);
+    mx = std::max(mx, b);
+    total += n;
+  }
+  if (total_records) *total_records = total;
+  return (mx + 255) & ~(int64_t)255;          // chunk stride: the largest rank, padded to 256 B
+}
+
+// records of every rank -> this rank's replay arena, rank order; returns the number of games added.  Records the
+// engine has already filed through this call are not sent again (Engine::records_exchanged watermark).
 int64_t comm_allgather_records(Engine& E, Comm* c) {
   if (!c) return E.replay_ingest_local();     // no communicator: a single-GPU run files its own records
   AGZ_REQUIRE(c->engine == &E, AGZ_BAD_ARGUMENT, "communicator belongs to another engine");
   hipStream_t s = E.stream();
   const int W = c->world;
-  // 1. pack
-  const int64_t need = E.records_packed_size();
-  DevBuf<uint8_t>& send = E.pack_scratch();
-  int64_t nb = 0, nrec = 0;
-  if (need) {
-    send.ensure((size_t)need);
-    nrec = E.pack_records_device(send.p, need, &nb);
+  // 1. what this rank has to send (headers only: the payload is packed straight into its slot of the receive buffer
+  //    once the stride is known -- the in-place form of ncclAllGather, no send buffer and no regrow-and-copy)
+  const int64_t first = E.records_exchanged();
+  int64_t mine[2] = {0, 0};
+  std::string my_error;
+  try {
+    mine[0] = std::max<int64_t>(0, E.records_count() - first);
+    mine[1] = E.records_packed_size(first);
+  } catch (const Error& x) {
+    mine[0] = -1;
+    mine[1] = x.status;
+    my_error = x.what();
   }
   // 2. counts
-  const int64_t mine[2] = {nrec, nb};
   AGZ_HIP(hipMemcpyAsync(c->d_counts.p, mine, sizeof(mine), hipMemcpyHostToDevice, s));
   AGZ_RCCL(rccl().AllGather(c->d_counts.p, c->d_counts.p + 2, 2, ncclInt64, c->comm, s));
   std::vector<int64_t> counts((size_t)2 * W);
   AGZ_HIP(hipMemcpyAsync(counts.data(), c->d_counts.p + 2, sizeof(int64_t) * counts.size(), hipMemcpyDeviceToHost, s));
   AGZ_HIP(hipStreamSynchronize(s));
-  int64_t mx = 0, total = 0;
-  for (int r = 0; r < W; ++r) {
-    AGZ_REQUIRE(counts[2 * r] >= 0 && counts[2 * r + 1] >= 0 && counts[2 * r + 1] % 8 == 0, AGZ_RCCL_ERROR,
-                "rank %d announced %lld records in %lld bytes", r, (long long)counts[2 * r], (long long)counts[2 * r + 1]);
-    mx = std::max(mx, counts[2 * r + 1]);
-    total += counts[2 * r];
-  }
+  if (mine[0] == -1) throw Error((agz_status)mine[1], my_error);
+  int64_t total = 0;
+  const int64_t stride = gather_plan(counts.data(), W, &total);
   if (total == 0) return 0;
-  mx = (mx + 255) & ~(int64_t)255;
   // 3. payload, padded to the largest rank (the pad bytes are never read: step 4 stops at each rank's count)
-  if ((int64_t)send.n < mx) {
-    DevBuf<uint8_t> bigger;
-    bigger.alloc((size_t)mx);
-    if (nb) AGZ_HIP(hipMemcpyAsync(bigger.p, send.p, (size_t)nb, hipMemcpyDeviceToDevice, s));
-    AGZ_HIP(hipStreamSynchronize(s));
-    std::swap(bigger.p, send.p);
-    std::swap(bigger.n, send.n);
-  }
-  c->d_recv.ensure((size_t)mx * W);
-  AGZ_RCCL(rccl().AllGather(send.p, c->d_recv.p, (size_t)mx, ncclUint8, c->comm, s));
+  c->d_recv.ensure((size_t)stride * W);        // grow-only; nothing of an earlier call is kept in it
+  int64_t nb = 0;
+  const int64_t nrec = E.pack_records_device(c->d_recv.p + (size_t)stride * c->rank, stride, &nb, first);
+  AGZ_REQUIRE(nrec == mine[0] && nb == mine[1], AGZ_RCCL_ERROR, "records changed during the exchange");
+  AGZ_RCCL(rccl().AllGather(c->d_recv.p + (size_t)stride * c->rank, c->d_recv.p, (size_t)stride, ncclUint8, c->comm, s));
   // 4 + 5. index on the device, compact into the arena
   std::vector<int64_t> coff((size_t)W), cbytes((size_t)W), cnrec((size_t)W);
   for (int r = 0; r < W; ++r) {
-    coff[r] = (int64_t)r * mx;
+    coff[r] = (int64_t)r * stride;
     cnrec[r] = counts[2 * r];
     cbytes[r] = counts[2 * r + 1];
   }
-  return E.replay_ingest_chunks(c->d_recv.p, coff, cbytes, cnrec);
+  const int64_t added = E.replay_ingest_chunks(c->d_recv.p, coff, cbytes, cnrec);
+  E.records_mark_exchanged(first + nrec);
+  return added;
 }
 
 // rank `root`'s parameters overwrite every other rank's replica (one flat f32 broadcast, 12-24 M parameters)

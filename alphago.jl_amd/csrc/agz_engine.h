@@ -39,10 +39,13 @@ class Engine {
   int64_t records_count();
   void record_header(int64_t k, agz_game_header* out);
   void record_game(int64_t k, int16_t* moves, float* pis, float* qs);
-  int64_t records_packed_size();
+  int64_t records_packed_size(int64_t first = 0);
   void records_export_packed(void* dst, int64_t capacity, bool is_device);
   void records_clear();
-  int64_t pack_records_device(uint8_t* dst, int64_t capacity, int64_t* nbytes);
+  int64_t pack_records_device(uint8_t* dst, int64_t capacity, int64_t* nbytes, int64_t first = 0);
+  // records [0, records_exchanged()) have been filed by agz_allgather_records since the last agz_records_clear
+  int64_t records_exchanged() const { return rec_sent_; }
+  void records_mark_exchanged(int64_t upto) { rec_sent_ = upto; }
   void record_features(int64_t k, float* out);
 
   // device replay arena: finished games of every rank, packed, resident in HBM
@@ -143,6 +146,7 @@ class Engine {
   int64_t rp_positions_ = 0;
   std::vector<int64_t> rp_off_;
   std::vector<agz_game_header> rp_hdr_;
+  int64_t rec_sent_ = 0;
 };
 
 // RCCL exchange (agz_comm.hip)
@@ -151,6 +155,9 @@ void comm_unique_id(uint8_t* out);
 Comm* comm_create(Engine& E, int rank, int world, const uint8_t* id);
 void comm_destroy(Comm* c);
 int64_t comm_allgather_records(Engine& E, Comm* c);
+// host logic of the exchange between its two collectives (also the C ABI's agz_gather_plan): checks the gathered
+// {records, bytes} pairs, returns the padded per-rank chunk size; throws AGZ_RCCL_ERROR naming the offending rank
+int64_t gather_plan(const int64_t* counts, int world, int64_t* total_records);
 int64_t comm_broadcast_weights(Engine& E, Comm* c, int root);
 
 }  // namespace agz

@@ -298,11 +298,11 @@ __host__ __device__ inline size_t packed_bytes(int A, int nm) {
 }
 
 // one workgroup per finished record k: copy it from the engine's record ring into dst + off[k]
-__global__ __launch_bounds__(256) void k_pack_records(View V, const int64_t* off, uint8_t* dst) {
-  const long k = blockIdx.x;
+__global__ __launch_bounds__(256) void k_pack_records(View V, const int64_t* off, uint8_t* dst, long first) {
+  const long k = first + blockIdx.x;
   const agz_game_header h = V.fin_hdr[k];
   const int nm = h.num_moves, mgl = V.max_game_length, A = V.A;
-  uint8_t* r = dst + off[k];
+  uint8_t* r = dst + off[blockIdx.x];
   if (threadIdx.x == 0) *reinterpret_cast<agz_game_header*>(r) = h;
   int16_t* mv = reinterpret_cast<int16_t*>(r + sizeof(agz_game_header));
   const size_t o_pi = (sizeof(agz_game_header) + sizeof(int16_t) * (size_t)nm + 3) & ~(size_t)3;
@@ -447,6 +447,10 @@ Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
 
 Engine::~Engine() {
   (void)hipStreamSynchronize(stream_);
+  // the trainers point into their networks (host-sync callback) and own device buffers: they go first, then the
+  // networks, and the stream they all enqueue on last
+  trainer_.reset();
+  trainer2_.reset();
   for (void* p : bufs_) (void)hipFree(p);
   net_.reset();
   net2_.reset();
@@ -463,6 +467,7 @@ void Engine::net_select(int which) {
 
 void Engine::start(int64_t total_games) {
   V_.total_games = total_games;
+  rec_sent_ = 0;
   AGZ_HIP(hipMemsetAsync(V_.counters, 0, sizeof(unsigned long long) * CT_COUNT, stream_));
   AGZ_HIP(hipMemsetAsync(V_.ar_hdr, 0, sizeof(int32_t) * 5 * (V_.games / 2 + 1), stream_));
   std::vector<GameState> gs(V_.games);
@@ -601,23 +606,25 @@ void Engine::record_game(int64_t k, int16_t* moves, float* pis, float* qs) {
 
 static size_t packed_record_bytes(const View& V, int nm) { return packed_bytes(V.A, nm); }
 
-int64_t Engine::records_packed_size() {
-  const int64_t n = records_count();
+// bytes of the packed form of records [first, count)
+int64_t Engine::records_packed_size(int64_t first) {
+  const int64_t n = records_count() - first;
+  if (n <= 0) return 0;
   std::vector<agz_game_header> h((size_t)n);
-  if (n) AGZ_HIP(hipMemcpy(h.data(), V_.fin_hdr, sizeof(agz_game_header) * (size_t)n, hipMemcpyDeviceToHost));
+  AGZ_HIP(hipMemcpy(h.data(), V_.fin_hdr + first, sizeof(agz_game_header) * (size_t)n, hipMemcpyDeviceToHost));
   size_t total = 0;
   for (auto& x : h) total += packed_record_bytes(V_, x.num_moves);
   return (int64_t)total;
 }
 
-// pack every finished record into `dst` (device memory, >= records_packed_size() bytes): one D2H of the
-// headers to lay the records out, one kernel to move them.  Returns the record count.
-int64_t Engine::pack_records_device(uint8_t* dst, int64_t capacity, int64_t* nbytes) {
-  const int64_t n = records_count();
+// pack the finished records [first, count) into `dst` (device memory, >= records_packed_size(first) bytes): one D2H
+// of the headers to lay the records out, one kernel to move them.  Returns the number of records packed.
+int64_t Engine::pack_records_device(uint8_t* dst, int64_t capacity, int64_t* nbytes, int64_t first) {
+  const int64_t n = records_count() - first;
   *nbytes = 0;
-  if (n == 0) return 0;
+  if (n <= 0) return 0;
   std::vector<agz_game_header> h((size_t)n);
-  AGZ_HIP(hipMemcpyAsync(h.data(), V_.fin_hdr, sizeof(agz_game_header) * (size_t)n, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(h.data(), V_.fin_hdr + first, sizeof(agz_game_header) * (size_t)n, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
   std::vector<int64_t> off((size_t)n);
   size_t total = 0;
@@ -628,7 +635,7 @@ int64_t Engine::pack_records_device(uint8_t* dst, int64_t capacity, int64_t* nby
   AGZ_REQUIRE((int64_t)total <= capacity, AGZ_BAD_ARGUMENT, "export buffer too small");
   s_i64a_.ensure((size_t)n);
   AGZ_HIP(hipMemcpyAsync(s_i64a_.p, off.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, stream_));
-  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)n), dim3(256), 0, stream_, V_, (const int64_t*)s_i64a_.p, dst);
+  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)n), dim3(256), 0, stream_, V_, (const int64_t*)s_i64a_.p, dst, (long)first);
   AGZ_HIP(hipGetLastError());
   AGZ_HIP(hipStreamSynchronize(stream_));      // `off` is stack-owned
   *nbytes = (int64_t)total;
@@ -750,13 +757,17 @@ int64_t Engine::replay_ingest_gathered(const void* buf, bool is_device, size_t n
   return replay_ingest_chunks(d, coff, cbytes, cnrec);
 }
 
+// files the engine's own finished records that no exchange has filed yet (the watermark rec_sent_ moves; the
+// record ring itself is the caller's to clear)
 int64_t Engine::replay_ingest_local() {
-  const int64_t need = records_packed_size();
+  const int64_t need = records_packed_size(rec_sent_);
   if (need == 0) return 0;
   s_pack_.ensure((size_t)need);
   int64_t nb = 0;
-  const int64_t n = pack_records_device(s_pack_.p, need, &nb);
-  return replay_ingest_chunks(s_pack_.p, {0}, {nb}, {n});
+  const int64_t n = pack_records_device(s_pack_.p, need, &nb, rec_sent_);
+  const int64_t added = replay_ingest_chunks(s_pack_.p, {0}, {nb}, {n});
+  rec_sent_ += n;
+  return added;
 }
 
 void Engine::replay_header(int64_t k, agz_game_header* out) const {
@@ -892,6 +903,7 @@ void Engine::replay_batch(const int64_t* game, const int32_t* ply, int B, float*
 }
 
 void Engine::records_clear() {
+  rec_sent_ = 0;
   AGZ_HIP(hipMemsetAsync(V_.counters + CT_RECORDED, 0, sizeof(unsigned long long), stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
 }

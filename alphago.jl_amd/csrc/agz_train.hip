@@ -411,6 +411,12 @@ Trainer::Trainer(Net& net, hipStream_t s) : net_(net), stream_(s) {
 }
 Trainer::~Trainer() { net_.set_host_sync(nullptr); }
 
+// The epsilon of TRAINING-mode BatchNorm.  A checkpoint's epsilon is the one its inference statistics were folded
+// with (bson_weights stores 0 for the Flux <= 0.7 dumps the reference ships: their sigma already contains it), and
+// 1 / sqrt(batch variance + 0) is inf on a dead channel -- 0 * inf = NaN, which Momentum then spreads to every
+// parameter.  Training never goes below Flux's default 1e-5 (BatchNorm(...; eps = 1f-5)).
+static inline float train_eps(float eps) { return eps > 1e-5f ? eps : 1e-5f; }
+
 void Trainer::reset() { have_vel_ = false; }
 
 // host parameters (Flux layouts) -> training layouts on the device.  Convolutions: Wt[cout][tap][cin_pad], the layout
@@ -585,7 +591,7 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
     zero_sums(kC);
     hipLaunchKernelGGL(k_colsums, dim3(kC / 64, RS), dim3(256), 0, s, (const float*)U(l), M, (int)kC, sums);
     hipLaunchKernelGGL(k_bn_fwd, g1(M * kC), dim3(256), 0, s, (const float*)U(l), M, (int)kC, (const double*)sums,
-                       (const float*)P4(l, 2).theta.p, (const float*)P4(l, 3).theta.p, net_.conv(l)->eps, res, O(l), 1, ST(l));
+                       (const float*)P4(l, 2).theta.p, (const float*)P4(l, 3).theta.p, train_eps(net_.conv(l)->eps), res, O(l), 1, ST(l));
   };
   conv_bn(0, d_x32_.p, nullptr);
   for (int blk = 0; blk < t; ++blk) {          // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32
@@ -605,11 +611,11 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
   zero_sums(2);
   hipLaunchKernelGGL(k_colsums, dim3(1, RS), dim3(256), 0, s, (const float*)cv, M, 1, sums);
   hipLaunchKernelGGL(k_bn_fwd, g1(M), dim3(256), 0, s, (const float*)cv, M, 1, (const double*)sums, (const float*)Gv.theta.p,
-                     (const float*)BEv.theta.p, net_.conv(AGZ_L_VALUE_CONV)->eps, (const float*)nullptr, hv, 1, st_v);
+                     (const float*)BEv.theta.p, train_eps(net_.conv(AGZ_L_VALUE_CONV)->eps), (const float*)nullptr, hv, 1, st_v);
   zero_sums(2);
   hipLaunchKernelGGL(k_colsums, dim3(1, RS), dim3(256), 0, s, (const float*)cp, M, 2, sums);
   hipLaunchKernelGGL(k_bn_fwd, g1(M * 2), dim3(256), 0, s, (const float*)cp, M, 2, (const double*)sums,
-                     (const float*)Gp.theta.p, (const float*)BEp.theta.p, net_.conv(AGZ_L_POLICY_CONV)->eps,
+                     (const float*)Gp.theta.p, (const float*)BEp.theta.p, train_eps(net_.conv(AGZ_L_POLICY_CONV)->eps),
                      (const float*)nullptr, hp, 1, st_p);
   hipLaunchKernelGGL(k_dense_fwd, dim3(1, B), dim3(256), 0, s, (const float*)hv, 0, P, (const float*)W1.theta.p,
                      (const float*)B1.theta.p, B, P, 256, 1, d1);

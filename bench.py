@@ -139,6 +139,11 @@ def main():
                          "f32s = the f32 network with Winograd operands split into two f16 halves (fp16 MFMA, f32-grade results)")
     ap.add_argument("--no-alt-precision", action="store_true",
                     help="skip the extra (untimed for `value`) leg that repeats the K steps with --precision f32s")
+    ap.add_argument("--generation", type=int, default=0, metavar="G",
+                    help="after the timed K steps keep playing, untimed for `value`: a warm-up until G games have ended "
+                         "naturally, then a window until G more have; the line gains a `generation` object with SURVEY.md 8d's "
+                         "generation rate (sum of position.n of the games that ended in the window / wall time) next to the "
+                         "steady-state rate of the same window (0 = off; 256 takes about two minutes)")
     ap.add_argument("--single-device-test", action="store_true",
                     help="testing only: every rank uses cuda:0 and gloo, to exercise the multi-rank code path on a 1-GPU box")
     args = ap.parse_args()
@@ -243,11 +248,58 @@ def main():
     # The one exchange step of the path, outside the timed region: every rank's finished records
     # are all-gathered into every rank's device replay arena by libagz itself (agz_allgather_records: RCCL over
     # xGMI, device to device).  torch.distributed only carries the 128-byte RCCL unique id to the other ranks.
+    # SURVEY.md 8d's own definition, on request: games played to their natural end (selfplay.jl:22-43), slots recycled
+    generation = None
+    if args.generation > 0 and world == 1:
+        G = args.generation
+        import numpy as np
+        g0 = eng.stats()["games_finished"]
+        tw = time.perf_counter()
+        while eng.stats()["games_finished"] - g0 < G and time.perf_counter() - tw < 900.0:
+            eng.step(25)
+        warm_s = time.perf_counter() - tw
+        eng.records_clear()
+        q0 = eng.stats()
+        tg0 = time.perf_counter()
+        while True:
+            eng.step(25)
+            q1 = eng.stats()                       # synchronises
+            if q1["games_finished"] - q0["games_finished"] >= G or time.perf_counter() - tg0 > 900.0:
+                break
+        wall = time.perf_counter() - tg0
+        recs = eng.records()
+        nm = np.array([r["num_moves"] for r in recs], np.int64)
+        gd = {k: q1[k] - q0[k] for k in ("positions", "evals", "games_finished", "resigned_games", "steps", "terminal_visits")}
+        generation = {
+            "what": f"window in which {G} games ended naturally (resignation, two passes or the move limit), after an untimed "
+                    f"warm-up in which {G} others did; slots recycled throughout",
+            "generation_rate": float(nm.sum()) / wall, "steady_state_rate": gd["positions"] / wall, "unit": "positions/s",
+            "generation_positions": int(nm.sum()), "steady_state_positions": gd["positions"], "wall_s": wall,
+            "steps": gd["steps"], "ms_per_step": 1e3 * wall / max(gd["steps"], 1), "games_finished": gd["games_finished"],
+            "resigned_games": gd["resigned_games"], "records_read": len(recs), "records_dropped": q1["records_dropped"],
+            "game_length": {"mean": float(nm.mean()), "min": int(nm.min()), "max": int(nm.max())} if len(nm) else None,
+            "evals_per_position": gd["evals"] / max(gd["positions"], 1), "terminal_visits": gd["terminal_visits"],
+            "batch_fill": gd["evals"] / max(gd["steps"] * 8 * args.games, 1), "warmup_s": warm_s,
+            "note": "generation_rate counts the moves of the games that ENDED in the window (8d), steady_state_rate the moves "
+                    "PLAYED in it (bench.py's `value` definition); they differ while the population of game ages is not stationary",
+        }
+        eng.records_clear()
+
     exchange = None
-    if dist is not None and not args.single_device_test:
+    exchange_hung = False
+    if dist is not None:
+        # the timed region of the headline config sees no game end (2 of ~76 moves per game); the exchange needs
+        # finished games: keep playing, untimed, until this rank has some (bounded)
+        for _ in range(16):
+            if eng.records_count() >= 4:
+                break
+            eng.step(50)
         # RCCL prints a version banner on stdout when a communicator is created; stdout must carry exactly one
         # JSON line, so the exchange leg runs with fd 1 pointed at stderr.  It also runs on a watchdog: a
         # collective that never completes (a rank missing, a fabric problem) must not swallow the self-play number.
+        # --single-device-test (every rank on cuda:0, where RCCL refuses two ranks on one device) runs the SAME leg
+        # with gloo carrying the two collectives: pack, count check / stride (agz_gather_plan), payload, device-side
+        # indexing and compaction into the arena are the C ABI's either way (Engine.allgather_records_hosted).
         import threading
         sys.stdout.flush()
         saved_fd = os.dup(1)
@@ -256,20 +308,36 @@ def main():
 
         def _exchange():
             try:
-                ids = [ag.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                comm = eng.comm_create(rank, world, ids[0])
-                barrier()
-                e0 = time.perf_counter()
-                added = eng.allgather_records(comm)
+                own = eng.records_count()
+                if args.single_device_test:
+                    barrier()
+                    e0 = time.perf_counter()
+                    added = eng.allgather_records_hosted()
+                    how = ("host-carried: agz_records_export_packed -> gloo all_gather (counts, then payload padded by "
+                           "agz_gather_plan) -> agz_replay_ingest_gathered")
+                else:
+                    ids = [ag.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    comm = eng.comm_create(rank, world, ids[0])
+                    barrier()
+                    e0 = time.perf_counter()
+                    added = eng.allgather_records(comm)
+                    how = "agz_allgather_records (count exchange + padded in-place ncclAllGather, device to device)"
                 eng.sync()
                 e1 = time.perf_counter()
-                box["ok"] = {"collective": "agz_allgather_records (count exchange + padded ncclAllGather, device to device)",
-                             "games_in_arena": added, "positions_in_arena": eng.replay_positions(),
-                             "ms": 1e3 * (e1 - e0), "own_games": eng.records_count()}
-                eng.comm_destroy(comm)
+                # every rank must now hold the same arena: sum of everybody's finished games, rank order
+                chk = torch.tensor([own, added, eng.replay_positions()], dtype=torch.int64, device=rdev)
+                allc = [torch.zeros_like(chk) for _ in range(world)]
+                dist.all_gather(allc, chk)
+                allc = [[int(v) for v in t.tolist()] for t in allc]
+                box["ok"] = {"collective": how, "games_in_arena": added, "positions_in_arena": eng.replay_positions(),
+                             "ms": 1e3 * (e1 - e0), "own_games": own, "own_games_by_rank": [c[0] for c in allc],
+                             "consistent": all(c[1] == sum(x[0] for x in allc) and c[2] == allc[0][2] for c in allc)}
+                eng.records_clear()
+                if not args.single_device_test:
+                    eng.comm_destroy(comm)
             except Exception as ex:      # the exchange leg must never take the self-play number down with it
-                box["err"] = str(ex)
+                box["err"] = f"{type(ex).__name__}: {ex}"
 
         th = threading.Thread(target=_exchange, daemon=True)
         th.start()
@@ -279,8 +347,6 @@ def main():
         sys.stdout.flush()
         os.dup2(saved_fd, 1)
         os.close(saved_fd)
-    else:
-        exchange_hung = False
 
     if s1["pool_exhausted"]:
         raise SystemExit("node pool exhausted during the benchmark: results invalid")
@@ -353,6 +419,8 @@ def main():
             "end_to_end_executed_mfma_frac": value * fpos * wino_ratio / (world * peak * 1e12),
             "roofline": roofline,
         }
+        if generation is not None:
+            out["generation"] = generation
         if exchange is not None:
             out["exchange"] = exchange
         if alt is not None:

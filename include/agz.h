@@ -292,10 +292,20 @@ agz_status agz_comm_unique_id(uint8_t* id_out /* [AGZ_COMM_ID_BYTES] */);
 agz_status agz_comm_create(agz_engine* e, int32_t rank, int32_t world, const uint8_t* id, agz_comm** out);
 void agz_comm_destroy(agz_comm* c);
 /* all-gather the finished records of every rank (what agz_records_* shows on each) into THIS rank's replay
- * arena, rank 0's games first: count exchange + one padded ncclAllGather, device to device; the caller
- * follows up with agz_records_clear.  comm == NULL: single-GPU run, files the engine's own records.
- * added_out (may be NULL) = games appended.  Collective: every rank of the communicator must call it. */
+ * arena, rank 0's games first: count exchange + one padded in-place ncclAllGather, device to device.  Records
+ * this call has already filed are not sent again (a second call without new finished games adds nothing);
+ * agz_records_clear empties the record ring and resets that mark.  comm == NULL: single-GPU run, files the
+ * engine's own records.  added_out (may be NULL) = games appended.  Collective: every rank of the
+ * communicator must call it; a rank that fails before the payload collective announces that in the count
+ * collective and EVERY rank returns AGZ_RCCL_ERROR (nobody is left waiting in ncclAllGather). */
 agz_status agz_allgather_records(agz_engine* e, agz_comm* comm, int64_t* added_out);
+/* The host logic between the two collectives of that exchange, for a host that carries the bytes with its own
+ * library (MPI.jl, Distributed, torch.distributed/gloo) and finishes with agz_replay_ingest_gathered:
+ * counts[2r], counts[2r+1] = {agz_records_count, agz_records_packed_size} of rank r as gathered (a rank that could
+ * not pack sends {-1, its agz_status}).  Checks every pair and returns the chunk stride (largest rank, padded to
+ * 256 B) each rank pads its packed export to; total_records_out may be NULL.  AGZ_RCCL_ERROR names the
+ * offending rank (text via agz_last_error(NULL)).  Pure host code: needs no engine and no GPU. */
+agz_status agz_gather_plan(const int64_t* counts, int32_t world, int64_t* chunk_stride_out, int64_t* total_records_out);
 /* overwrite every rank's weight replica with rank `root`'s parameters of the selected network (after a
  * training step on one rank); nfloats_out may be NULL.  Collective. */
 agz_status agz_broadcast_weights(agz_engine* e, agz_comm* comm, int32_t root, int64_t* nfloats_out);

@@ -56,6 +56,9 @@ def test_allgather_records_through_the_c_abi_over_rccl():
         assert int(a["game_id"]) % 2 == 1 and same_record(a, by_id[int(a["game_id"])]) and same_record(b, a), k
     ids = sorted(e0.replay_record(k)["game_id"] for k in range(11))
     assert ids == list(range(11))                                # game ids r, r + W, ...: the shards interleave
+    # records this call has filed once are not sent again (a second call used to re-ingest every game) ...
+    assert e0.allgather_records(comm) == 0 and e0.replay_count() == 16
+    assert e0.allgather_records(None) == 0 and e0.replay_count() == 16          # ... nor by the communicator-less form
     # a second generation appends; the engine's own ring is the caller's to clear
     e0.records_clear()
     assert e0.allgather_records(comm) == 0 and e0.replay_count() == 16

@@ -33,7 +33,8 @@ class Twin:
         w = torch.flip(w, dims=(2, 3))                                        # NNlib conv is a true convolution
         y = torch.nn.functional.conv2d(x, w, self.th[(l, K_B)], padding=k // 2)
         return torch.nn.functional.batch_norm(y, self.run[l][0], self.run[l][1], self.th[(l, K_GAMMA)], self.th[(l, K_BETA)],
-                                              training=training, momentum=0.1, eps=self.eps[l])
+                                              training=training, momentum=0.1,
+                                              eps=max(self.eps[l], 1e-5) if training else self.eps[l])
 
     def forward(self, feats, training):
         N, P, A, B = self.N, self.P, self.A, feats.shape[0]
