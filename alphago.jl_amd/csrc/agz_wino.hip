@@ -276,12 +276,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   const int P = N * N, TT = T * T;
   const int RPB = wino_rows_per_block(T);
   const long Mt = (long)(*d_count) * TT;
-  // workgroup -> (tile block, cout block): see k_wino_gemm (U of two cout blocks stays L2-resident per XCD,
-  // the two cout blocks of a tile block are neighbours on one XCD and share its V slab)
+  // workgroup -> (tile block, cout block): block b runs on XCD b % 8.  The four cout blocks of a tile block are four
+  // CONSECUTIVE workgroups of one XCD, so its V slab (1.7 MB) comes out of HBM once and is served to the other three from
+  // that XCD's L2.  Rounds 1-2 split a tile block over an XCD pair (two cout blocks each, so that the 3.3 MB of U an XCD
+  // needs stay in its 4 MB L2): V then crossed HBM twice -- 4.0 of the layer's 7.2 GB.  With all of U (6.5 MB) wanted by
+  // every XCD the U misses go to the Infinity Cache instead; measured -0.65 % per forward (A/B, same box) and V read once.
   const int bid = blockIdx.x;
   const int xcd = bid & 7, jb = bid >> 3;
-  const int cb = 2 * (xcd & 1) + (jb & 1);
-  const int tb = (xcd >> 1) + 4 * (jb >> 1);
+  const int cb = jb & 3;
+  const int tb = xcd + 8 * (jb >> 2);
   if ((long)tb * RPB >= Mt) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -713,7 +716,7 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s, int ns) {
   const int T = (N + 2) / 3;
   const int blocks = (int)wino_blocks(bcap, T);
-  const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm4
+  const int per_xcd = 4 * ((blocks + 7) / 8);   // see the placement comment in k_wino_gemm4
   const dim3 grid(8 * per_xcd), block(256);
   if (ns == kWinoStemStages) {                   // the stem: its output is always wanted in HBM (block 0's residual)
     constexpr int S = kWinoStemStages;

@@ -37,20 +37,22 @@ def f_eval(N, t):
     return 2.0 * P * (9 * 17 * 256 + t * 2 * 9 * 256 * 256) + 2.0 * P * 256 * 3 + 2.0 * (2 * P * (P + 1) + P * 256 + 256)
 
 
-def pmc_traffic(rows_per_launch, precision="f32"):
+def pmc_traffic(rows_per_launch, N, precision="f32"):
     """HBM bytes per tower-conv launch, from the committed rocprofv3 --pmc passes.
 
-    Hardware counters cannot be read from inside this process; FETCH_SIZE and WRITE_SIZE were
-    collected in two separate `rocprofv3 --pmc` runs of tools/nn_micro.py (same kernels, full
-    8192-position batch) and summarised into profiles/pmc_traffic.json as bytes per board-point row.
-    Scaled here by the average rows per launch of THIS run.  None if the file is absent."""
-    name = "pmc_traffic.json" if precision == "f32" else f"r02_pmc_traffic_{precision}.json"
-    path = os.path.join(ROOT, "profiles", name)
-    try:
-        d = json.load(open(path))
-        return d["bytes_per_row"] * rows_per_launch, f"profiles/{name} ({d['source']})"
-    except Exception:
-        return None, None
+    Hardware counters cannot be read from inside this process; FETCH_SIZE and WRITE_SIZE were collected in two
+    separate `rocprofv3 --pmc` runs of THIS command (tools/profile_r03.sh: same kernels, same batch) and summarised
+    by tools/pmc_traffic.py as bytes per board-point row.  Scaled here by the average rows per launch of THIS run.
+    None if no file exists for the board size and precision."""
+    for name in (f"r03_pmc_traffic_{N}x{N}_{precision}.json",) + (
+            ("pmc_traffic.json" if precision == "f32" else f"r02_pmc_traffic_{precision}.json",) if N == 9 else ()):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            d = json.load(open(path))
+            return d["bytes_per_row"] * rows_per_launch, f"profiles/{name} ({d['source']})"
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(N, tower, readouts, seconds):
@@ -358,7 +360,7 @@ def main():
         f16, f32s = args.precision == "f16", args.precision == "f32s"
         wino_ratio = 1.0 if f16 else 25.0 * T * T / (9.0 * N * N)   # executed / algorithmic multiplies of F(3x3,3x3)
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_src = (None, None) if N != 9 else pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), args.precision)
+        traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), N, args.precision)
         # The roofline object.  `achieved`/`frac` are what the MFMA pipe EXECUTES: Winograd F(3x3,3x3) needs 25
         # multiplies per 3x3 output tile and (cin, cout) pair instead of 81, all of them still f32, so the
         # honest fraction of the f32 MFMA peak is executed flops / time / peak (<= 1).  The rate in terms of the
@@ -378,7 +380,7 @@ def main():
                 "achieved": tb, "peak": 8000.0, "unit": "GB/s", "frac": tb / 8000.0 if tb else None,
                 "traffic": traffic, "traffic_source": traffic_src, "achieved_algorithmic": alg_tf,
                 "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
-                "note": "traffic = HBM bytes per layer from the PMC passes of the f32 form (same buffers, same bytes)",
+                "note": "traffic = HBM bytes per layer from the PMC passes named in traffic_source",
             }
         roofline = roofline if f32s else {
             "bound": "mfma",

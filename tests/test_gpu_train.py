@@ -3,10 +3,14 @@ device) against the float64 autograd twin tests/train_twin.py.  The reference ca
 broken at HEAD), so the twin is the pin; the twin itself is tied to the pinned oracle by its
 inference-mode forward (tests/test_train_twin.py, CPU).
 
-Bars: losses within 1e-5 relative; every parameter's update (theta_new - theta_old) within 2e-3 of the largest
-update of its tensor (f32 sums of up to B*P = 486 terms against float64) plus two f32 ulps of the parameter (a conv
-bias in front of a BatchNorm has no data gradient: its update is weight decay only, ~1e-6, below one ulp of
-2e-3 x that), BatchNorm running statistics 1e-5."""
+Bars: losses within 1e-5 relative; BatchNorm running statistics 1e-5; every parameter's update (theta_new -
+theta_old), as a fraction of the largest update of its tensor and after two f32 ulps of the parameter itself (it is
+stored in f32): within 1e-5 -- or, where f32 arithmetic itself cannot do that, within 4x the error a plain PyTorch
+float32 autograd of the same step makes on the same tensor.  Measured on MI355X (round 3): <= 1e-6 at the toy shapes
+(round 2's bar was 2e-3, which would have hidden a dropped tap on a small tensor); at the reference's shape (9x9, 21
+stacked convolutions, batch 32) the device step is 3.6e-3 from float64 on the stem's weights and torch float32 is
+1.7e-3...1.6e-2 on the same tensors: the gradient reaches the first layers through 20 BatchNorm backward passes, each a
+cancellation (dy - mean(dy) - xhat mean(dy xhat)) -- f32 roundoff class, not a kernel defect."""
 import numpy as np
 import pytest
 
@@ -35,9 +39,9 @@ def batch(N, B, seed):
 # batch_size = 32; its tower_height = 19 default differs only in depth); and B = 128 at 9x9, where the forward / dgrad
 # take launch_conv3x3_direct (no tap split) and the weight gradient the row-split k_wgrad3x3 + k_sum_parts path.
 CASES = [(5, 1, 8), (9, 2, 6), (5, 3, 8), (9, 10, 32), (9, 2, 128)]
-# measured worst update error per case, relative to the tensor's largest update (printed by the test; MI355X, round 3)
-# -- the bar is 10x the measurement, not the 2e-3 of round 2 that would have hidden a dropped tap on a small tensor
-UPDATE_BAR = {(5, 1, 8): 2e-3, (9, 2, 6): 2e-3, (5, 3, 8): 2e-3, (9, 10, 32): 2e-3, (9, 2, 128): 2e-3}
+# floor of the update bar per case = 10x the worst measured on MI355X (printed by the test): toy shapes measure <= 1e-6
+ABS_BAR = {(5, 1, 8): 1e-5, (9, 2, 6): 1e-5, (5, 3, 8): 1e-5, (9, 10, 32): 1e-5, (9, 2, 128): 3e-4}
+F32_FACTOR = 4.0      # above the floor: no further from float64 than 4x what torch float32 autograd is on that tensor
 
 
 @pytest.mark.parametrize("N,tower,B", CASES)
@@ -50,14 +54,17 @@ def test_train_step_matches_float64_twin(N, tower, B):
         eng.set_weights(l, 1, rng.uniform(-0.2, 0.2, n).astype(np.float32))
         eng.set_weights(l, 2, rng.uniform(-0.3, 0.3, n).astype(np.float32))
         eng.set_weights(l, 3, rng.uniform(0.5, 1.5, n).astype(np.float32))
+    import torch
     twin = Twin(N, tower, eng.get_weights)
+    twin32 = Twin(N, tower, eng.get_weights, dtype=torch.float32)      # the plain-PyTorch-fp32 yardstick
     before = {key: eng.get_weights(*key).copy() for key in eng.layers()}
-    worst = {}                                         # (layer, kind) -> worst |d update| / largest update of the tensor
-    bar = UPDATE_BAR[(N, tower, B)]
+    worst, worst32 = {}, {}                            # (layer, kind) -> worst |d update| / largest update of the tensor
+    floor, bad = ABS_BAR[(N, tower, B)], []
     for it in range(2):                                # the second step exercises the Momentum velocity
         feats, pi, z = batch(N, B, 10 + it)
         got = eng.train_step(feats, pi, z)
         want = twin.step(feats, pi, z)
+        twin32.step(feats, pi, z)
         assert np.allclose(got, want, rtol=1e-5, atol=1e-9), (it, got, want)
         for (l, k) in eng.layers():
             new = eng.get_weights(l, k)
@@ -65,17 +72,30 @@ def test_train_step_matches_float64_twin(N, tower, B):
                 continue
             ref = twin.param(l, k)
             if k in (K_MEAN, K_VAR):
-                assert np.allclose(new, ref, rtol=1e-5, atol=1e-6), (it, l, k)
+                # running statistics: 1e-5, or (second step, after parameters that already differ in their last bits) what
+                # the float32 twin itself is away from float64
+                tol = 1e-6 + 1e-5 * np.abs(ref)
+                d, d32 = np.abs(new - ref), np.abs(twin32.param(l, k).astype(np.float64) - ref)
+                if not (d <= np.maximum(tol, F32_FACTOR * d32.max())).all():
+                    bad.append((it, l, k, float(d.max()), float(d32.max())))
                 continue
             upd, upd_ref = new.astype(np.float64) - before[(l, k)], ref - before[(l, k)]
             scale = np.abs(upd_ref).max()
             ulp = 2.0 ** -23 * max(np.abs(ref).max(), 1e-30)        # the parameter itself is stored in f32
             err = np.abs(upd - upd_ref).max()
-            worst[(l, k)] = max(worst.get((l, k), 0.0), max(err - 2 * ulp, 0.0) / max(scale, 1e-300))
-            assert err <= bar * scale + 2 * ulp, (it, l, k, err, scale)
+            err32 = np.abs(twin32.param(l, k).astype(np.float64) - before[(l, k)] - upd_ref).max()
+            rel = max(err - 2 * ulp, 0.0) / max(scale, 1e-300)
+            rel32 = max(err32 - 2 * ulp, 0.0) / max(scale, 1e-300)
+            worst[(l, k)] = max(worst.get((l, k), 0.0), rel)
+            worst32[(l, k)] = max(worst32.get((l, k), 0.0), rel32)
+            if rel > max(floor, F32_FACTOR * rel32):
+                bad.append((it, l, k, rel, rel32))
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
-    print(f"\n[train parity {N}x{N} tower {tower} B {B}] worst update error / largest update: "
-          + ", ".join(f"layer {l} kind {k}: {e:.2e}" for (l, k), e in top))
+    print(f"\n[train parity {N}x{N} tower {tower} B {B}] worst update error / largest update (torch-f32 autograd on the "
+          f"same tensor): " + ", ".join(f"layer {l} kind {k}: {e:.2e} ({worst32[(l, k)]:.2e})" for (l, k), e in top)
+          + f"; tensors above {floor:g}: {sum(e > floor for e in worst.values())} of {len(worst)}; worst ratio to torch-f32 "
+          f"among those: {max([e / max(worst32[key], 1e-300) for key, e in worst.items() if e > floor] or [0.0]):.2f}")
+    assert not bad, bad[:8]
     # the step really moved the network, and inference now runs with the new parameters
     assert any(np.abs(eng.get_weights(*key) - before[key]).max() > 0 for key in eng.layers() if key[1] == 0)
     feats, _, _ = batch(N, B, 99)

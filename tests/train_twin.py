@@ -11,8 +11,12 @@ L_VCONV, L_PCONV, L_VFC1, L_VFC2, L_PFC = -1, -2, -3, -4, -5
 
 
 class Twin:
-    def __init__(self, N, tower, get):
-        """get(layer, kind) -> flat float32 numpy array (e.g. Engine.get_weights)"""
+    def __init__(self, N, tower, get, dtype=DT):
+        """get(layer, kind) -> flat float32 numpy array (e.g. Engine.get_weights).  dtype = torch.float32 makes the
+        twin a plain PyTorch fp32 autograd of the same step: what f32 arithmetic costs at this depth, the yardstick
+        for the device step's own distance from the float64 twin (tests/test_gpu_train.py)"""
+        DT = dtype
+        self.dt = dtype
         self.N, self.tower = N, tower
         self.P, self.A = N * N, N * N + 1
         self.convs = list(range(1 + 2 * tower)) + [L_VCONV, L_PCONV]
@@ -38,7 +42,7 @@ class Twin:
 
     def forward(self, feats, training):
         N, P, A, B = self.N, self.P, self.A, feats.shape[0]
-        x = torch.tensor(np.asarray(feats, np.float64).reshape(B, 17, N, N).transpose(0, 1, 3, 2).copy(), dtype=DT)   # [b,c,i,j]
+        x = torch.tensor(np.asarray(feats, np.float64).reshape(B, 17, N, N).transpose(0, 1, 3, 2).copy(), dtype=self.dt)   # [b,c,i,j]
         h = torch.relu(self._conv_bn(0, 3, 17, 256, x, training))
         for blk in range(self.tower):
             t = torch.relu(self._conv_bn(1 + 2 * blk, 3, 256, 256, h, training))
@@ -58,7 +62,7 @@ class Twin:
         """returns (total, policy, value, reg) before the update"""
         B = feats.shape[0]
         logp, v = self.forward(feats, True)
-        pi_t, z_t = torch.tensor(np.asarray(pi, np.float64)), torch.tensor(np.asarray(z, np.float64))
+        pi_t, z_t = torch.tensor(np.asarray(pi, np.float64), dtype=self.dt), torch.tensor(np.asarray(z, np.float64), dtype=self.dt)
         lp = 0.01 * (-(pi_t * logp).sum() / B)
         lv = 0.01 * ((v - z_t) ** 2).mean()
         lr = 1e-4 * sum((t ** 2).sum() for t in self.th.values())

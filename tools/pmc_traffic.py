@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
-tools/nn_micro.py --batches B --algos 1.
+"""profiles/*pmc_traffic*.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the bench.py command
+itself (round 3, tools/profile_r03.sh; round 2 used tools/nn_micro.py --batches B --algos 1: same kernels).
+Usage: pmc_traffic.py <positions per launch> <board N> <FETCH dir> <WRITE dir>
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python tools/nn_micro.py --batches 8192 --algos 1 --iters 2
   rocprofv3 --pmc WRITE_SIZE ...                                  -d gpurun_out/pmc_WRITE_SIZE ...
@@ -51,10 +52,10 @@ for k, cs in agg.items():
         total += sum(v for c, v in per_kernel[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE"))
 layers = max(layers, 1)
 print(json.dumps({
-    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/nn_micro.py --batches {B}, gfx950; KiB counters; "
+    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the bench.py command, <= {B} positions per launch, {N}x{N}, gfx950; KiB counters; "
               "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads (raw kept); bytes of ALL "
               "tower-layer Winograd kernels of the run / number of tower-layer GEMM dispatches (the stem's 8-stage GEMM is listed, not counted)",
     "rows_per_launch": rows, "tower_layer_dispatches": layers, "bytes_per_launch": total / layers, "bytes_per_row": total / layers / rows,
-    "algorithmic_bytes_per_row": 2.5 * 256 * 4,
+    "algorithmic_bytes_per_row": 2.5 * 256 * 4, "board": N,
     "per_kernel_total_bytes": per_kernel, "per_kernel_dispatches": counts,
 }, indent=1))
