@@ -161,8 +161,10 @@ size_t wino_weight_floats(int ns = kWinoStages);
 size_t wino_v_floats(int bcap, int T);
 // x -> V (the 25 transformed planes as GEMM stage images); needed in front of the first Winograd layer, and
 // in front of every layer when the board's tiles do not pack into whole-board tile blocks (!wino_fusable)
+// fixup: dense tile blocks (!wino_fusable(N), e.g. 19x19) whose previous GEMM already emitted the V of every tile whose
+// 5x5 patch lies inside its block: only the remaining rows (the ends of every block, the rows past the batch) are done
 void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s,
-                    int ns = kWinoStages);
+                    int ns = kWinoStages, bool fixup = false);
 // V, U -> y (if y != NULL: affine, residual, ReLU applied) and / or the NEXT layer's V (if vnext != NULL)
 void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s,

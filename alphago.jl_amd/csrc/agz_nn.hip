@@ -588,7 +588,7 @@ void Net::reserve(int bcap) {
   d_ph_.alloc(rows * 2);
   if (tower_ > 0) {
     d_vimg_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
-    if (wino_fusable(N_)) d_vimg2_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
+    d_vimg2_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
   }
   bcap_ = bcap;
 }
@@ -695,51 +695,47 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
     const bool split = precision_ == 2 && winograd_;
     const float* usrc = split ? d_uwino_s_.p : d_uwino_.p;
     if (split) sc = d_scale_s_.p;
-    if (winograd_ && wino_fusable(N_)) {
-      // Winograd with the input transform of layer l+1 fused into the GEMM of layer l: only the first layer needs
+    if (winograd_) {
+      // Winograd with the input transform of layer l+1 fused into the GEMM of layer l: only the first layer needs a full
       // k_wino_in; conv1 of a block leaves nothing but V in HBM, conv2 leaves the block output (the next residual,
-      // and the heads' input) and the next block's V
+      // and the heads' input) and the next block's V.  Whole-board tile blocks (N <= 12) emit every tile's V from the
+      // epilogue.  Dense blocks (19x19) emit the tiles whose 5x5 patch lies inside their block -- three quarters of
+      // them -- and a fix-up pass of k_wino_in transforms the rest from y, which every layer therefore writes
+      // (round 2 ran the full k_wino_in in front of every layer there: 20 % of a step, MFMA pipe idle).
+      const bool dense = !wino_fusable(N_);
       float *vcur = d_vimg_.p, *vnxt = d_vimg2_.p;
       if (stem_wino) {
         launch_wino_in(d_x32, vnxt, d_count, bcap, N_, split, stream_, kWinoStemStages);
         launch_wino_gemm(vnxt, split ? d_ustem_s_.p : d_ustem_.p, split ? d_scale_s_.p + (size_t)2 * tower_ * kC : d_scale_.p,
                          d_shift_.p, nullptr, a, vcur, d_count, bcap, N_, 1, split, stream_, kWinoStemStages);
+        if (dense) launch_wino_in(a, vcur, d_count, bcap, N_, split, stream_, kWinoStages, true);
       }
       for (int blk = 0; blk < tower_; ++blk) {     // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32
         const int l1 = 2 * blk, l2 = 2 * blk + 1;
         const bool last = blk + 1 == tower_;
         timed([&] {
-          launch_wino_gemm(vcur, usrc + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, nullptr, vnxt,
+          launch_wino_gemm(vcur, usrc + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, dense ? t : nullptr, vnxt,
                            d_count, bcap, N_, 1, split, stream_);
+          if (dense) launch_wino_in(t, vnxt, d_count, bcap, N_, split, stream_, kWinoStages, true);
         });
         timed([&] {
           launch_wino_gemm(vnxt, usrc + uper * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, a, b,
                            last ? nullptr : vcur, d_count, bcap, N_, 1, split, stream_);
+          if (dense && !last) launch_wino_in(b, vcur, d_count, bcap, N_, split, stream_, kWinoStages, true);
         });
         std::swap(a, b);
       }
-    } else {
-      if (stem_wino) {
-        launch_wino_in(d_x32, d_vimg_.p, d_count, bcap, N_, split, stream_, kWinoStemStages);
-        launch_wino_gemm(d_vimg_.p, split ? d_ustem_s_.p : d_ustem_.p,
-                         split ? d_scale_s_.p + (size_t)2 * tower_ * kC : d_scale_.p, d_shift_.p, nullptr, a, nullptr, d_count,
-                         bcap, N_, 1, split, stream_, kWinoStemStages);
-      }
-      auto conv = [&](int l, const float* in, const float* res, float* out) {
-        timed([&] {
-          if (winograd_) {
-            launch_wino_in(in, d_vimg_.p, d_count, bcap, N_, split, stream_);
-            launch_wino_gemm(d_vimg_.p, usrc + uper * l, sc + (size_t)l * kC, sh + (size_t)l * kC, res, out, nullptr,
-                             d_count, bcap, N_, 1, split, stream_);
-          } else {
-            hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, in, d_wtower_.p + per * l,
-                               sc + (size_t)l * kC, sh + (size_t)l * kC, res, out, d_count, N_, 1);
-          }
-        });
-      };
+    } else {                                         // the direct implicit GEMM (agz_net_set_winograd(0)); the stem ran above
       for (int blk = 0; blk < tower_; ++blk) {
-        conv(2 * blk, a, nullptr, t);
-        conv(2 * blk + 1, t, a, b);
+        const int l1 = 2 * blk, l2 = 2 * blk + 1;
+        timed([&] {
+          hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)a, d_wtower_.p + per * l1,
+                             sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, (const float*)nullptr, t, d_count, N_, 1);
+        });
+        timed([&] {
+          hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)t, d_wtower_.p + per * l2,
+                             sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, (const float*)a, b, d_count, N_, 1);
+        });
         std::swap(a, b);
       }
     }
@@ -799,11 +795,11 @@ void Net::launch_tower_conv_once(const int* d_count, int bcap) {
     const bool split = precision_ == 2;
     launch_wino_gemm(d_vimg_.p, split ? d_uwino_s_.p : d_uwino_.p, split ? d_scale_s_.p : d_scale_.p + kC, d_shift_.p + kC,
                      d_a_.p, d_t_.p, d_vimg2_.p, d_count, bcap, N_, 1, split, stream_);
-  } else if (winograd_) {
+  } else if (winograd_) {                       // dense tile blocks: the GEMM emits most of the next V, the fix-up pass the rest
     const bool split = precision_ == 2;
-    launch_wino_in(d_a_.p, d_vimg_.p, d_count, bcap, N_, split, stream_);
     launch_wino_gemm(d_vimg_.p, split ? d_uwino_s_.p : d_uwino_.p, split ? d_scale_s_.p : d_scale_.p + kC, d_shift_.p + kC,
-                     nullptr, d_t_.p, nullptr, d_count, bcap, N_, 1, split, stream_);
+                     d_a_.p, d_t_.p, d_vimg2_.p, d_count, bcap, N_, 1, split, stream_);
+    launch_wino_in(d_t_.p, d_vimg2_.p, d_count, bcap, N_, split, stream_, kWinoStages, true);
   }
   else
   hipLaunchKernelGGL((k_conv3x3_mfma<kC>), dim3(grid), dim3(256), 0, stream_, (const float*)d_a_.p,

@@ -99,14 +99,29 @@ __host__ __device__ inline int wino_rows_per_block(int T) {
 }
 __host__ __device__ inline bool wino_whole_boards(int T) { return wino_rows_per_block(T) % (T * T) == 0 && T * T <= WT; }
 
+// Densely packed tile blocks (19x19: 49 tiles per board do not fill 64 rows in whole boards): is the 5x5 input patch of
+// tile (ti, tj), sitting in row `row` of its block, made of tiles of the SAME block?  Its neighbours (ti + di, tj + dj)
+// are rows row + di T + dj.  If so the GEMM epilogue of the layer before can emit this tile's V like it does for
+// whole-board blocks (k_wino_gemm4 phase 2); the tiles at the two ends of a block -- about a quarter at 19x19 -- are
+// left to k_wino_in in its FIXUP form.  Both kernels decide with this one function.
+__host__ __device__ __forceinline__ bool wino_tile_fused(int T, int row, int ti, int tj) {
+  const int lo = (ti > 0 ? T : 0) + (tj > 0 ? 1 : 0), hi = (ti < T - 1 ? T : 0) + (tj < T - 1 ? 1 : 0);
+  return row - lo >= 0 && row + hi < WT;
+}
+
 // ------------------------------------------------------------------ input transform
 
+// B^T x, five values.  ONE arithmetic for both producers of V -- k_wino_in (scalars) and the GEMM epilogue's fused
+// transform (channel pairs, bt5p below): with dense tile blocks the same tile is transformed by one or the other
+// depending on where its batch row puts it in a block, and a network output must not depend on the batch row (tree
+// parity rests on it).  Every multiply-add is an EXPLICIT fma, so that the compiler's contraction choices cannot differ
+// between the two kernels (3 x2 - x3 rounds differently fused and unfused).
 __device__ __forceinline__ void bt5(float x0, float x1, float x2, float x3, float x4, float* r) {
-  r[0] = 2.f * x0 - x1 - 2.f * x2 + x3;
-  r[1] = 2.f * x1 + x2 - x3;
-  r[2] = -2.f * x1 + 3.f * x2 - x3;
   r[3] = x3 - x1;
-  r[4] = 2.f * x1 - x2 - 2.f * x3 + x4;
+  r[0] = __builtin_fmaf(2.f, x0 - x2, r[3]);
+  r[4] = __builtin_fmaf(-2.f, r[3], x4 - x2);
+  r[1] = __builtin_fmaf(2.f, x1, x2 - x3);
+  r[2] = __builtin_fmaf(-2.f, x1, __builtin_fmaf(3.f, x2, -x3));
 }
 
 // grid = 2 x tile blocks (32-tile halves); 256 threads = 32 tiles x 8 channel pairs (= 4 consecutive stages x 2
@@ -116,7 +131,10 @@ __device__ __forceinline__ void bt5(float x0, float x1, float x2, float x3, floa
 // stages are skewed by 8 dwords each: a ds_write_b64 is served 16 lanes (2 tiles x 8 lanes) at a time over 32
 // banks, and with that skew the 16 lanes cover all 32 banks exactly once.
 // NS = stages = input channels / 4: 64 for a tower layer, 8 for the stem (17 feature planes padded to 32)
-template <int TPB, bool NT, bool SPLIT = false, int NS = WNS>
+// FIXUP (dense tile blocks only): only the tiles the previous layer's GEMM epilogue could not emit (!wino_tile_fused:
+// the ends of every block) and the rows past the batch (zeros) are transformed and stored; the other rows of the
+// image are already in place and are not touched.
+template <int TPB, bool NT, bool SPLIT = false, int NS = WNS, bool FIXUP = false>
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T) {
   static_assert(TPB == 32, "the copy-out below moves 32-row chunks");
@@ -135,9 +153,10 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
   const int tl = threadIdx.x / LPT;                 // tile within this part
   const int row = part * TPB + tl;                  // row of the 64-row stage image
   const long tile = (long)tb * RPB + row;
-  const bool live = row < RPB && tile < Mt;
+  bool live = row < RPB && tile < Mt;
   const int b = live ? (int)(tile / TT) : 0, t = live ? (int)(tile % TT) : 0;
   const int ti = t / T, tj = t % T;
+  if (FIXUP && live && wino_tile_fused(T, row, ti, tj)) live = false;       // in place already: nothing to read
   int off[25];                                      // element offsets < 2^31 (8192 x 361 x 256 = 7.6e8)
 #pragma unroll
   for (int u = 0; u < 5; ++u)
@@ -154,6 +173,13 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
   else *reinterpret_cast<float2*>(mine + 25 * CH) = make_float2(0.f, 0.f);
   float* gdst = vimg + (long)tb * NS * A_STAGE + part * CH;
   const int cq = threadIdx.x / TPB, cl = threadIdx.x % TPB;      // copy-out: 8 chunks per round, 32 lanes each
+  bool copy_row = true;                                         // FIXUP: only the rows this kernel computed leave
+  if (FIXUP) {
+    const int crow = part * TPB + cl;
+    const long ctile = (long)tb * RPB + crow;
+    const int ct = (int)(ctile % TT);
+    copy_row = !(crow < RPB && ctile < Mt && wino_tile_fused(T, crow, ct / T, ct % T));
+  }
   for (int sg = 0; sg < NS / SP; ++sg) {
     const int st = sg * SP + sl;
     float2 d[25];
@@ -199,6 +225,7 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       const f32x4 v = *reinterpret_cast<const f32x4*>(img + s4 * IMG + xi * CH + cl * 4);
       f32x4* gp = reinterpret_cast<f32x4*>(gdst + (long)(sg * SP + s4) * A_STAGE + (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4) + cl * 4);
+      if (FIXUP && !copy_row) continue;
       if (NT) __builtin_nontemporal_store(v, gp);     // V is 2.8x the activations and is read back much later
       else *gp = v;
     }
@@ -544,17 +571,22 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const int row = lane;
     const long tile = (long)tb * RPB + row;
     const bool live = row < RPB && tile < Mt;
-    const int t = live ? (int)(tile % TT) : 0, lb = row / TT;
+    const int t = live ? (int)(tile % TT) : 0;
     const int ti = t / T, tj = t % T;
+    // Whole-board blocks (N <= 12): every tile's patch is in the block, all 64 rows are written (dead rows as zeros).
+    // Dense blocks (19x19): only the tiles whose neighbours are rows of this block (wino_tile_fused); the others, and
+    // the dead rows, are k_wino_in<FIXUP>'s.
+    const bool emit = wino_whole_boards(T) || (live && wino_tile_fused(T, row, ti, tj));
     int poff[25];
 #pragma unroll
     for (int u = 0; u < 5; ++u)
 #pragma unroll
       for (int v = 0; v < 5; ++v) {
         const int pi = 3 * ti - 1 + u, pj = 3 * tj - 1 + v;
-        const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
-        // the point lives in tile (pi / 3, pj / 3) of the same board, output k = (pi % 3) * 3 + pj % 3
-        poff[u * 5 + v] = ok ? ((pi % 3) * 3 + pj % 3) * WT + lb * TT + (pi / 3) * T + pj / 3 : -1;      // = X
+        const bool ok = live && emit && pi >= 0 && pi < N && pj >= 0 && pj < N;
+        // the point lives in tile (pi / 3, pj / 3) of the same board = row + (pi / 3 - ti) T + (pj / 3 - tj) of this
+        // block, output k = (pi % 3) * 3 + pj % 3
+        poff[u * 5 + v] = ok ? ((pi % 3) * 3 + pj % 3) * WT + row + (pi / 3 - ti) * T + (pj / 3 - tj) : -1;      // = X
       }
     int pbase[25], pxm[25];            // float offset of point X's row in img, and its swizzle X & 15
 #pragma unroll
@@ -574,15 +606,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
         d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + pbase[q] + 4 * (sl ^ pxm[q])) : z;
       }
       float* g = vnext + ((long)tb * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
-      // B^T d B on channel PAIRS (v_pk_*_f32: two channels per VALU instruction; no MFMA runs beside this)
-      // B^T x with shared subexpressions (9 packed operations instead of 15; small integers times f32: the
-      // association only moves the last bit, and every later layer's V comes from this one code path)
-      auto bt5p = [](f32x2 x0, f32x2 x1, f32x2 x2, f32x2 x3, f32x2 x4, f32x2* r) {
+      // B^T d B on channel PAIRS (v_pk_*_f32: two channels per VALU instruction; no MFMA runs beside this): the
+      // arithmetic of bt5 above, operation for operation (9 packed operations per five values)
+      auto bt5p = [](f32x2 x0, f32x2 x1, f32x2 x2, f32x2 x3, f32x2 x4, f32x2* r) {      // bt5, two channels at a time
+        const f32x2 two = {2.f, 2.f}, mtwo = {-2.f, -2.f}, three = {3.f, 3.f};
         r[3] = x3 - x1;
-        r[0] = 2.f * (x0 - x2) + r[3];
-        r[4] = (x4 - x2) - 2.f * r[3];
-        r[1] = 2.f * x1 + (x2 - x3);
-        r[2] = (3.f * x2 - x3) - 2.f * x1;
+        r[0] = __builtin_elementwise_fma(two, x0 - x2, r[3]);
+        r[4] = __builtin_elementwise_fma(mtwo, r[3], x4 - x2);
+        r[1] = __builtin_elementwise_fma(two, x1, x2 - x3);
+        r[2] = __builtin_elementwise_fma(mtwo, x1, __builtin_elementwise_fma(three, x2, -x3));
       };
       f32x2 vv[25][2];
 #pragma unroll
@@ -627,7 +659,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
           if (v4[0] + v4[3] == 123.456f) *gp = v4;
           continue;
         }
-        __builtin_nontemporal_store(v4, gp);      // 1.9 GB per layer, read back a whole layer later: keep it out of L2
+        if (emit) __builtin_nontemporal_store(v4, gp);      // 1.9 GB per layer, read back a whole layer later: keep it out of L2
       }
     }
   }
@@ -698,9 +730,16 @@ static long wino_blocks(int bcap, int T) {
 size_t wino_v_floats(int bcap, int T) { return (size_t)wino_blocks(bcap, T) * WNS * A_STAGE; }
 bool wino_fusable(int N) { return wino_whole_boards((N + 2) / 3); }
 
-void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s, int ns) {
+void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, int N, bool split, hipStream_t s, int ns,
+                    bool fixup) {
   const int T = (N + 2) / 3;
   const int blocks = (int)wino_blocks(bcap, T);
+  if (fixup) {      // the rows the previous GEMM's epilogue left out (dense tile blocks; a tower layer's 64 stages)
+    AGZ_REQUIRE(ns == kWinoStages && !wino_whole_boards(T), AGZ_BAD_ARGUMENT, "fix-up transform: dense tile blocks, tower layers");
+    if (split) hipLaunchKernelGGL((k_wino_in<32, true, true, WNS, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+    else hipLaunchKernelGGL((k_wino_in<32, true, false, WNS, true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+    return;
+  }
   if (ns == kWinoStemStages) {
     if (split) hipLaunchKernelGGL((k_wino_in<32, true, true, kWinoStemStages>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
     else hipLaunchKernelGGL((k_wino_in<32, true, false, kWinoStemStages>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
