@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("resign_disable_fraction", C.c_double),
         ("seed", C.c_uint64), ("game_id_base", C.c_uint64), ("game_id_stride", C.c_uint64),
         ("max_nodes_per_game", C.c_int32), ("device", C.c_int32), ("external_network", C.c_int32),
-        ("stagger_moves", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
+        ("reserved1", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
     ]
 
 
@@ -190,6 +190,7 @@ def load():
         "agz_debug_draws": (i32, [E, u64, u64, u32, i32, f64, f64p]),
         "agz_debug_math": (i32, [E, i32, f64p, f64p, i32, f64p]),
         "agz_debug_counters": (i32, [E, C.POINTER(C.c_uint64), i32]),
+        "agz_debug_set_stagger": (i32, [E, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -327,7 +327,7 @@ int32_t agz_abi_layout(const char* name, int32_t* out, int32_t cap) {
     AGZ_OFF(agz_config, dirichlet_noise_weight); AGZ_OFF(agz_config, resign_threshold);
     AGZ_OFF(agz_config, resign_disable_fraction); AGZ_OFF(agz_config, seed); AGZ_OFF(agz_config, game_id_base);
     AGZ_OFF(agz_config, game_id_stride); AGZ_OFF(agz_config, max_nodes_per_game); AGZ_OFF(agz_config, device);
-    AGZ_OFF(agz_config, external_network); AGZ_OFF(agz_config, stagger_moves);
+    AGZ_OFF(agz_config, external_network); AGZ_OFF(agz_config, reserved1);
     AGZ_OFF(agz_config, record_capacity_games); AGZ_OFF(agz_config, arena_mode);
   } else if (n == "agz_stats") {
     AGZ_SZ(agz_stats);
@@ -554,6 +554,9 @@ int32_t agz_debug_counters(agz_engine* e, uint64_t* out, int32_t cap) {
   int32_t n = -1;
   (void)guard(e, [&](agz::Engine& E) { n = E.debug_counters(out, cap); });
   return n;
+}
+agz_status agz_debug_set_stagger(agz_engine* e, int32_t moves) {
+  return guard(e, [&](agz::Engine& E) { E.debug_set_stagger(moves); });
 }
 
 }  // extern "C"

@@ -31,6 +31,7 @@ class Engine {
   void step(int nsteps);
   void stats(agz_stats* out);
   int debug_counters(uint64_t* out, int cap);
+  void debug_set_stagger(int moves);
   int select_external();
   void leaf_features_external(float* feats_out);
   void incorporate_external(const float* pi, const float* v);

@@ -398,8 +398,7 @@ static void validate(const agz_config& c) {
   AGZ_REQUIRE(c.num_readouts >= 1, AGZ_BAD_ARGUMENT, "num_readouts must be >= 1");
   AGZ_REQUIRE(c.parallel_readouts >= 1 && c.parallel_readouts <= kMaxPar, AGZ_BAD_ARGUMENT,
               "parallel_readouts %d not in 1..%d", c.parallel_readouts, kMaxPar);
-  AGZ_REQUIRE(!c.arena_mode || (c.games % 2 == 0 && c.stagger_moves == 0), AGZ_BAD_ARGUMENT,
-              "arena_mode needs an even number of slots and no stagger");
+  AGZ_REQUIRE(!c.arena_mode || c.games % 2 == 0, AGZ_BAD_ARGUMENT, "arena_mode needs an even number of slots");
 }
 
 Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
@@ -544,6 +543,11 @@ void Engine::incorporate_external(const float* pi, const float* v) {
   AGZ_HIP(hipStreamSynchronize(stream_));
   external_batch_ = 0;
   external_batch2_ = 0;
+}
+
+void Engine::debug_set_stagger(int moves) {
+  AGZ_REQUIRE(moves >= 0 && !cfg_.arena_mode, AGZ_BAD_ARGUMENT, "stagger: >= 0 moves, not in arena_mode");
+  V_.stagger = moves;            // the View travels to the kernels by value: effective from the next launch
 }
 
 int Engine::debug_counters(uint64_t* out, int cap) {

@@ -25,7 +25,7 @@ inline void fill_dims(View& V, const agz_config& c) {
   V.tau = ((V.P / 12) / 2) * 2;                           // mcts_play.jl:19
   V.arena = c.arena_mode ? 1 : 0;
   V.two_player = c.two_player_mode || c.arena_mode;       // evaluate(): both players are two_player_mode
-  V.stagger = c.stagger_moves;
+  V.stagger = 0;                 // agz_debug_set_stagger (bench / soak tests only)
   V.cap = c.max_nodes_per_game > 0 ? c.max_nodes_per_game : 16 * c.num_readouts + 256;
   V.fin_cap = c.record_capacity_games > 0 ? c.record_capacity_games : 2 * c.games + 64;
   V.total_games = 0;

@@ -434,13 +434,16 @@ void Trainer::upload() {
   const int t = net_.tower(), L = 1 + 2 * t;
   if (params_.empty())
     for (size_t i = 0; i < (size_t)4 * L + 8 + 6; ++i) params_.emplace_back(new Param);
+  // every array is enqueued, ONE synchronisation at the end (one per array was 4 L + 14 round trips);
+  // the repacked convolution weights live in `staged` until then
+  std::vector<std::vector<float>> staged;
+  staged.reserve((size_t)L);
   auto put = [&](Param& p, const std::vector<float>& h) {
     p.n = h.size();
     p.theta.ensure(p.n);
     p.grad.ensure(p.n);
     if (p.vel.n < p.n) { p.vel.ensure(p.n); have_vel_ = false; }
     AGZ_HIP(hipMemcpyAsync(p.theta.p, h.data(), sizeof(float) * p.n, hipMemcpyHostToDevice, stream_));
-    AGZ_HIP(hipStreamSynchronize(stream_));
   };
   for (int l = 0; l < L; ++l) {
     const ConvHost& c = *net_.conv(l);
@@ -451,7 +454,8 @@ void Trainer::upload() {
         for (int b = 0; b < 3; ++b)
           for (int ci = 0; ci < c.cin; ++ci)
             w[((size_t)o * 9 + (2 - a) + 3 * (2 - b)) * cinp + ci] = c.w[a + 3 * (b + 3 * (ci + (size_t)c.cin * o))];
-    put(*params_[4 * l + 0], w);
+    staged.push_back(std::move(w));
+    put(*params_[4 * l + 0], staged.back());
     put(*params_[4 * l + 1], c.b);
     put(*params_[4 * l + 2], c.gamma);
     put(*params_[4 * l + 3], c.beta);
@@ -472,6 +476,7 @@ void Trainer::upload() {
   if (!have_vel_)
     for (auto& p : params_) AGZ_HIP(hipMemsetAsync(p->vel.p, 0, sizeof(float) * p->n, stream_));
   have_vel_ = true;
+  AGZ_HIP(hipStreamSynchronize(stream_));      // the host sources (`staged`, the ConvHost / DenseHost vectors) are free again
 }
 
 // the inverse of upload(), plus the running BatchNorm statistics; marks the inference packs dirty
@@ -480,18 +485,12 @@ void Trainer::download() {
   auto get = [&](Param& p, std::vector<float>& h) {
     h.resize(p.n);
     AGZ_HIP(hipMemcpyAsync(h.data(), p.theta.p, sizeof(float) * p.n, hipMemcpyDeviceToHost, stream_));
-    AGZ_HIP(hipStreamSynchronize(stream_));
   };
+  // all copies in flight, one synchronisation, then the convolution weights back into Flux order
+  std::vector<std::vector<float>> wt((size_t)L);
   for (int l = 0; l < L; ++l) {
     ConvHost& c = *net_.conv(l);
-    const int cinp = l == 0 ? kCinStemPad : kC;
-    std::vector<float> w;
-    get(*params_[4 * l + 0], w);
-    for (int o = 0; o < kC; ++o)
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b)
-          for (int ci = 0; ci < c.cin; ++ci)
-            c.w[a + 3 * (b + 3 * (ci + (size_t)c.cin * o))] = w[((size_t)o * 9 + (2 - a) + 3 * (2 - b)) * cinp + ci];
+    get(*params_[4 * l + 0], wt[l]);
     get(*params_[4 * l + 1], c.b);
     get(*params_[4 * l + 2], c.gamma);
     get(*params_[4 * l + 3], c.beta);
@@ -508,6 +507,17 @@ void Trainer::download() {
     DenseHost& d = *net_.dense(l);
     get(*params_[k++], d.w);
     get(*params_[k++], d.b);
+  }
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  for (int l = 0; l < L; ++l) {
+    ConvHost& c = *net_.conv(l);
+    const int cinp = l == 0 ? kCinStemPad : kC;
+    const std::vector<float>& w = wt[l];
+    for (int o = 0; o < kC; ++o)
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          for (int ci = 0; ci < c.cin; ++ci)
+            c.w[a + 3 * (b + 3 * (ci + (size_t)c.cin * o))] = w[((size_t)o * 9 + (2 - a) + 3 * (2 - b)) * cinp + ci];
   }
   net_.mark_dirty();
 }

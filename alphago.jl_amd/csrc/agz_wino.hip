@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     // phase 1.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     const int col = wn * 32 + l31;
     const float sc = scale[cb * WC + col], sh = shift[cb * WC + col];
-    const bool relu_now = relu != 0;       // ReLU here, on the way into the image: phase 1b only has to copy
+    const float relu_lo = relu ? 0.f : -3.0e38f;      // ReLU here, on the way into the image (one v_max either way): phase 1b only has to copy
     // whole 16-register tuples at a time (element e of a tuple = tile row e of the C/D map): extracting single
     // elements of AGPR-resident tuples made hipcc copy entire tuples back and forth (330 instructions per e)
     f32x16 o[9];
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 #pragma unroll
           for (int k = 0; k < 9; ++k) {
             float v = o[k][e0 + ee] * sc + sh + rr[ee][k];
-            if (relu_now) v = fmaxf(v, 0.f);
+            v = fmaxf(v, relu_lo);
             p0[ee][k * (WT * WC)] = v;
           }
       }
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       pxm[q] = poff[q] & 15;
     }
     // a V image row is one plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1 (wino_v_off)
-    const bool swap = (row >> 4) & 1;
+    const int sw2 = 2 * ((row >> 4) & 1);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll 1
     for (int sl = wave; sl < WC / WK; sl += 4) {      // (unrolling by 2 for ILP: no change)
@@ -603,7 +603,17 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 #pragma unroll
       for (int q = 0; q < 25; ++q) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + pbase[q] + 4 * (sl ^ pxm[q])) : z;
+        if constexpr (SPLIT) {
+          d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + pbase[q] + 4 * (sl ^ pxm[q])) : z;
+        } else {
+          // the lane's two channel pairs in the order its V row wants them (rows with bit 4 set store pair 1 first): two
+          // 8-byte reads at lane-dependent halves of the unit instead of 104 selects per task on the way out
+          const float* u = img + pbase[q] + 4 * (sl ^ pxm[q]);
+          const f32x2 zz = {0.f, 0.f};
+          const f32x2 a = poff[q] >= 0 ? *reinterpret_cast<const f32x2*>(u + sw2) : zz;
+          const f32x2 b = poff[q] >= 0 ? *reinterpret_cast<const f32x2*>(u + (2 - sw2)) : zz;
+          d[q] = (f32x4){a[0], a[1], b[0], b[1]};
+        }
       }
       float* g = vnext + ((long)tb * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
       // B^T d B on channel PAIRS (v_pk_*_f32: two channels per VALU instruction; no MFMA runs beside this): the
@@ -638,9 +648,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
         }
       }
 #pragma unroll
-      for (int xi = 0; xi < 26; ++xi) {
-        const f32x2 z2 = {0.f, 0.f};
-        const f32x2 p0 = xi < 25 ? vv[xi < 25 ? xi : 0][0] : z2, p1 = xi < 25 ? vv[xi < 25 ? xi : 0][1] : z2;
+      for (int xi = 0; xi < WXI; ++xi) {              // (the 26th plane slot of an image is padding nobody multiplies with)
+        const f32x2 p0 = vv[xi][0], p1 = vv[xi][1];
         f32x4 v4;
         if constexpr (SPLIT) {
           _Float16 ah[4], al[4];
@@ -651,8 +660,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
           const h8 pk = {ah[0], ah[1], ah[2], ah[3], al[0], al[1], al[2], al[3]};
           v4 = __builtin_bit_cast(f32x4, pk);
         } else {
-          const f32x2 lo = swap ? p1 : p0, hi2 = swap ? p0 : p1;
-          v4 = (f32x4){lo[0], lo[1], hi2[0], hi2[1]};
+          v4 = (f32x4){p0[0], p0[1], p1[0], p1[1]};        // (already in the row's pair order: see the reads above)
         }
         f32x4* gp = reinterpret_cast<f32x4*>(g + (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4));
         if (X == 3) {

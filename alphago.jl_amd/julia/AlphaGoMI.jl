@@ -40,7 +40,7 @@ struct AgzConfig
   c_puct::Float64; dirichlet_noise_weight::Float64; resign_threshold::Float64
   resign_disable_fraction::Float64
   seed::UInt64; game_id_base::UInt64; game_id_stride::UInt64
-  max_nodes_per_game::Int32; device::Int32; external_network::Int32; stagger_moves::Int32
+  max_nodes_per_game::Int32; device::Int32; external_network::Int32; reserved1::Int32
   record_capacity_games::Int32; arena_mode::Int32
 end
 

@@ -70,7 +70,7 @@ typedef struct {
   int32_t max_nodes_per_game;      /* 0 = auto (16*num_readouts + 256) */
   int32_t device;                  /* HIP device ordinal */
   int32_t external_network;        /* 1: pi/v are supplied by the caller (duck-typed network) */
-  int32_t stagger_moves;           /* bench only: random opening prefix of up to this many moves */
+  int32_t reserved1;               /* 0 (rounds 1-2 kept a bench-only knob here: now agz_debug_set_stagger, agz_debug.h) */
   int32_t record_capacity_games;   /* finished-game record slots kept on the device; 0 = auto */
   int32_t arena_mode;              /* 1: evaluate() arena -- slots 2i / 2i+1 are the Black / White player of one
                                     * game with networks 0 / 1 (agz_net_select); `games` must be even */

@@ -24,6 +24,12 @@ agz_status agz_debug_math(agz_engine* e, int32_t op, const double* x, const doub
  * -DAGZ_TIMING_EXPERIMENTS build of libagz.so writes (tools/pre_phases.py); returns how many there are, copies
  * min(cap, that) of them.  Synchronises. */
 int32_t agz_debug_counters(agz_engine* e, uint64_t* out, int32_t cap);
+/* Bench / soak-test population shaping, never part of the reference's behaviour: every game started from now on (also
+ * the recycled ones) begins with a random legal opening prefix of up to `moves` plies and its first search gets a
+ * random fraction of the readout budget, so that concurrent games sit at mixed stages and phases from the first timed
+ * step (that first, shortened move is not counted as a position).  0 = off (the default).  Call it before
+ * agz_selfplay_start; not available in arena_mode. */
+agz_status agz_debug_set_stagger(agz_engine* e, int32_t moves);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ class AgzConfig(C.Structure):
         ("resign_disable_fraction", C.c_double),
         ("seed", C.c_uint64), ("game_id_base", C.c_uint64), ("game_id_stride", C.c_uint64),
         ("max_nodes_per_game", C.c_int32), ("device", C.c_int32), ("external_network", C.c_int32),
-        ("stagger_moves", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
+        ("reserved1", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
     ]
 
 
