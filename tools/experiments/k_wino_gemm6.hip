@@ -44,7 +44,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int G6C = 64;                          // couts per workgroup
 constexpr int G6_G = 4;                          // planes per pass (64 accumulator registers); plane 24 has a pass of its own
 constexpr int G6_UNIT = 16 * 256;                // floats per LDS unit: 8 (channel group, plane) steps x (V piece | U piece)
-constexpr int G6_NBUF = 4;                       // unit buffers: the DMA runs three units ahead
+constexpr int G6_NBUF = 4;                       // unit buffers: the DMA runs up to four units ahead
 constexpr int G6_CH = 32;                        // couts per epilogue chunk
 constexpr int G6_IMG = WT * 9 * G6_CH;           // epilogue tile image: 18,432 floats = 73,728 B
 constexpr int G6_LDS = G6_IMG > G6_NBUF * G6_UNIT ? G6_IMG : G6_NBUF * G6_UNIT;
@@ -55,6 +55,19 @@ constexpr int G6_LDS = G6_IMG > G6_NBUF * G6_UNIT ? G6_IMG : G6_NBUF * G6_UNIT;
 // group with a conflict-free ds_read_b128; the accumulator layout (lane = cout, rows 4 apart in the two lane halves)
 // writes with 2-way conflicts, which a ds_write_b32 hides.
 __device__ __forceinline__ int g6_img_off(int X, int c) { return X * G6_CH + 4 * ((c >> 2) ^ ((X >> 1) & 7)) + (c & 3); }
+
+// fold weights: plane xi = (i, j) adds g6_fold[xi][3 i' + j'] = A^T[i'][i] A^T[j'][j] times its accumulator to output (i', j')
+// (A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1]; 121 of the 225 entries are non-zero, all of them exact in f32)
+struct G6Fold { float w[WXI][9]; };
+static constexpr G6Fold g6_make_fold() {
+  G6Fold f{};
+  const int AT[3][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 1}};
+  for (int xi = 0; xi < WXI; ++xi)
+    for (int i2 = 0; i2 < 3; ++i2)
+      for (int j2 = 0; j2 < 3; ++j2) f.w[xi][i2 * 3 + j2] = (float)(AT[i2][xi / 5] * AT[j2][xi % 5]);
+  return f;
+}
+__constant__ G6Fold g6_fold = g6_make_fold();
 
 #ifdef AGZ_TIMING_EXPERIMENTS
 // per workgroup: {hw id | xcc id << 32, start, K loops done, end} on the 100 MHz wall clock (who shares a CU, and when)
@@ -156,7 +169,7 @@ __device__ __attribute__((noinline)) void g6_emit(const float* img, const int* p
         }
 }
 
-// MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
+// MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images; bit 2: a residual is added.
 // NS: stages of the K loop (input channels / 4): 64, or 8 for the stem
 // X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
 //   1 = K loops only; 4 = no DMA after the prologue; 5 = no MFMA
@@ -165,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_gemm6(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
+  constexpr bool HASRES = (MODE & 4) != 0;       // a residual is added (res != NULL)
   constexpr int UN = NS / 2;                     // units of a four-plane pass (8 channels each)
   constexpr int FULL = 6 * UN;                   // units of the six four-plane passes; then NS / 8 units of plane 24 (32 channels each)
   constexpr int TOTAL = FULL + NS / 8;           // units per tile: 200 (25 for the stem)
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_gemm6(
     glds16s(src, (unsigned)lane * 16u, lds0 + (unsigned)((v % G6_NBUF) * G6_UNIT + p * 256) * 4u);
   };
 #pragma unroll
-  for (int v = 0; v < 3; ++v)
+  for (int v = 0; v < G6_NBUF; ++v)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (v < TOTAL) dma(v, q);
@@ -235,21 +249,40 @@ __global__ __launch_bounds__(256, 2) void k_wino_gemm6(
   // the nine running outputs as 144 scalars, not nine 16-register tuples: they never feed an MFMA, and 32-bit live
   // ranges leave the register allocator the room that nine more 512-bit tuples beside the accumulators do not
   float o[9][16];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
 
   // operand offsets inside a unit (floats): within a piece the lane's channel pair h = hi of row r sits at
   // r * 4 + 2 * ((hi + (r >> 4)) & 1) (wino_v_off)
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
   const int aoff = arow * 4 + 2 * ((hi + (arow >> 4)) & 1);
   const int boff = 8 * 256 + brow * 4 + 2 * ((hi + (brow >> 4)) & 1);
-  constexpr int LA = 2, RING = 3;        // operands are read LA steps ahead of their MFMAs
+  // Operands are read LA = 2 steps ahead of their MFMAs through a ring of four register pairs (8 steps per unit: the ring
+  // slots are compile-time across units).  The unit barrier sits in the READ stream, two steps before a unit's last MFMA
+  // (k_wino_gemm4's scheme): the MFMAs of steps 6 and 7 cover the barrier and the first LDS latencies of the next unit,
+  // and once a wave is past the barrier of unit w nobody reads w's buffer any more -- it takes the DMA of unit w + 4.
+  constexpr int LA = 2, RING = 4;
   float2 ra[RING], rb[RING];
+  static_assert(TOTAL >= G6_NBUF, "prologue");
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // unit 0 of this wave; units 1..3 (12 pieces) may be in flight
+  __syncthreads();
+#pragma unroll
+  for (int s0 = 0; s0 < LA; ++s0) {
+    ra[s0] = *reinterpret_cast<const float2*>(lds + aoff + s0 * 256);
+    rb[s0] = *reinterpret_cast<const float2*>(lds + boff + s0 * 256);
+  }
 
   int u = 0;
   // One pass: NPL planes P0 .. P0 + NPL - 1 through all the input channels (units of 8 / NPL channel groups), then their
   // share of A^T M A into the running outputs: plane (i, j) adds A^T[i'][i] A^T[j'][j] M_ij to output (i', j')
   // (A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1]: 121 multiply-adds per element over the 25 planes, all weights exact).
-  auto pass = [&](auto p0_c, auto npl_c) {
-    constexpr int P0 = decltype(p0_c)::value, NPL = decltype(npl_c)::value;
+  // (ONE copy of the code for the six four-plane passes -- the plane index is run-time, the fold weights come from
+  // g6_fold through SGPRs -- and one for plane 24: unrolled per pass the kernel was 95 KB of code, and a CU pair's 64 KB
+  // instruction cache turned every straight-line section, executed once per tile, into ~60 cycles per instruction.)
+  auto pass = [&](int P0, auto npl_c) {
+    constexpr int NPL = decltype(npl_c)::value;
     constexpr int UNP = NS * NPL / 8;               // units of this pass
     f32x16 acc[NPL];
 #pragma unroll
@@ -258,29 +291,32 @@ __global__ __launch_bounds__(256, 2) void k_wino_gemm6(
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #pragma unroll 1
     for (int g = 0; g < UNP; ++g, ++u) {
-      // unit u has landed (this wave's pieces: the eight of units u + 1, u + 2 may still be in flight; everybody's: the
-      // barrier), and every wave has finished reading unit u - 1, whose buffer the DMA of unit u + 3 now overwrites
-      if (X == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (u + 2 < TOTAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (u + 1 < TOTAL) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
       const float* L = lds + (u % G6_NBUF) * G6_UNIT;
-      const bool more = u + 3 < TOTAL && X != 4;
-#pragma unroll
-      for (int s = 0; s < LA; ++s) {
-        ra[s % RING] = *reinterpret_cast<const float2*>(L + aoff + s * 256);
-        rb[s % RING] = *reinterpret_cast<const float2*>(L + boff + s * 256);
-      }
+      const float* Ln = lds + ((u + 1) % G6_NBUF) * G6_UNIT;
+      const bool next = u + 1 < TOTAL;
+      const bool more = u + G6_NBUF < TOTAL && X != 4;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {              // step s = (channel group s / NPL, plane s % NPL)
+        if (s == 8 - LA && next) {
+          // unit u + 1 has landed for this wave (units u + 2, u + 3 may be in flight), then for everybody
+          if (X == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (u + 3 < TOTAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if (u + 2 < TOTAL) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
         if (s + LA < 8) {
           ra[(s + LA) % RING] = *reinterpret_cast<const float2*>(L + aoff + (s + LA) * 256);
           rb[(s + LA) % RING] = *reinterpret_cast<const float2*>(L + boff + (s + LA) * 256);
+        } else if (next) {
+          ra[(s + LA) % RING] = *reinterpret_cast<const float2*>(Ln + aoff + (s + LA - 8) * 256);
+          rb[(s + LA) % RING] = *reinterpret_cast<const float2*>(Ln + boff + (s + LA - 8) * 256);
         }
-        if ((s & 1) == 0) {                      // four pieces per wave and unit, one in front of every other step
+        // the four pieces of unit u + 4 go into this unit's own buffer, behind its barrier: two here, two at the head of u + 1
+        if (s >= 8 - LA || s < 2) {
           __builtin_amdgcn_sched_barrier(0);
-          if (more) dma(u + 3, s >> 1);
+          if (s >= 8 - LA) { if (more) dma(u + G6_NBUF, s - (8 - LA)); }
+          else if (u > 0 && u - 1 + G6_NBUF < TOTAL && X != 4) dma(u - 1 + G6_NBUF, 2 + s);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (X != 5) {
@@ -291,52 +327,39 @@ __global__ __launch_bounds__(256, 2) void k_wino_gemm6(
         }
       }
     }
-    constexpr int AT[3][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 1}};
+    // the fold: every plane's accumulator times its nine weights into the nine running outputs
+    float w[NPL][9];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) w[pl][q] = g6_fold.w[P0 + pl][q];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
-        const int xi = P0 + pl, pi = xi / 5, pj = xi % 5;
         const float m = acc[pl][e];
+        if (NPL == 1) {
+          o[8][e] += m;                           // plane 24 = (4, 4): weight 1 on output (2, 2) only
+        } else {
 #pragma unroll
-        for (int i2 = 0; i2 < 3; ++i2)
-#pragma unroll
-          for (int j2 = 0; j2 < 3; ++j2) {
-            const int w = AT[i2][pi] * AT[j2][pj];
-            if (w == 0) continue;
-            // the first plane that reaches output (i2, j2): (i, j) = (i2 ? 1 : 0, j2 ? 1 : 0) -- it defines the running sum
-            const bool first = xi == (i2 ? 1 : 0) * 5 + (j2 ? 1 : 0);
-            if (first) o[i2 * 3 + j2][e] = (float)w * m;
-            else o[i2 * 3 + j2][e] += (float)w * m;
-          }
+          for (int q = 0; q < 9; ++q) o[q][e] = __builtin_fmaf(w[pl][q], m, o[q][e]);
+        }
       }
       // (an element pair at a time: left to interleave all sixteen, the scheduler keeps their temporaries alive beside the
       // 208 registers that must survive, and the allocator answers by parking outputs in scratch for the whole tile)
       if (e & 1) __builtin_amdgcn_sched_barrier(0);
     }
-    // The fold happens HERE: an empty asm that takes the outputs this pass wrote pins their computation in front of the
-    // next pass's (volatile) DMA and wait statements.  Without it the compiler sinks the fold arithmetic towards the
-    // outputs' first use in the epilogue and keeps every pass's ACCUMULATORS alive in scratch instead (1.2 KB per lane).
+    // The fold happens HERE: an empty asm that takes the outputs pins their computation in front of the next pass's
+    // (volatile) DMA and wait statements.  Without it the compiler sinks the fold arithmetic towards the outputs' first
+    // use in the epilogue and keeps every pass's ACCUMULATORS alive in scratch instead (1.2 KB per lane).
 #pragma unroll
-    for (int i2 = 0; i2 < 3; ++i2)
+    for (int q = 0; q < 9; ++q)
 #pragma unroll
-      for (int j2 = 0; j2 < 3; ++j2) {
-        bool touched = false;
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) touched = touched || AT[i2][(P0 + pl) / 5] * AT[j2][(P0 + pl) % 5] != 0;
-        if (touched) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(o[i2 * 3 + j2][e]));
-        }
-      }
+      for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(o[q][e]));
   };
-  pass(std::integral_constant<int, 0>{}, std::integral_constant<int, G6_G>{});
-  pass(std::integral_constant<int, 4>{}, std::integral_constant<int, G6_G>{});
-  pass(std::integral_constant<int, 8>{}, std::integral_constant<int, G6_G>{});
-  pass(std::integral_constant<int, 12>{}, std::integral_constant<int, G6_G>{});
-  pass(std::integral_constant<int, 16>{}, std::integral_constant<int, G6_G>{});
-  pass(std::integral_constant<int, 20>{}, std::integral_constant<int, G6_G>{});
-  pass(std::integral_constant<int, 24>{}, std::integral_constant<int, 1>{});
+#pragma unroll 1
+  for (int p4 = 0; p4 < 6; ++p4) pass(G6_G * p4, std::integral_constant<int, G6_G>{});
+  pass(WXI - 1, std::integral_constant<int, 1>{});
 #ifdef AGZ_TIMING_EXPERIMENTS
   if (tid == 0 && bid < 16384) g6_trace[bid][2] = g6_now();
 #endif
@@ -363,22 +386,20 @@ __global__ __launch_bounds__(256, 2) void k_wino_gemm6(
   float* img = lds;
   const int col = l31;                              // cout inside the chunk
   const float sc = scale[cb * G6C + wn * G6_CH + col], sh = shift[cb * G6C + wn * G6_CH + col];
-  const bool relu_now = relu != 0;
-  // One chunk.  OWNER is compile-time and the two wave classes take separate code paths (below), so that the nine
-  // output tuples are dead in the owner's phases 1b / 2 (which need the registers) and alive only in code that
-  // merely waits: with one loop over c and `if (wn == c)` inside, o stays live through phase 2 and spills (1.2 KB of
-  // scratch per lane, and the spill traffic's vmcnt waits end up inside the K loop).  Every path executes the same
-  // number of barriers per chunk.
-  auto chunk = [&](int c, auto owner_c) {
-    constexpr bool OWNER = decltype(owner_c)::value;
+  const float relu_lo = relu ? 0.f : -3.0e38f;      // ReLU as one v_max either way
+  // One chunk at a time; the same code for both (the instruction cache decides: see the pass loop).  The owners' phases 1b
+  // and 2 are a function call: they want ~250 registers, and inlined here they push running outputs into scratch.
+#pragma unroll 1
+  for (int c = 0; c < 2; ++c) {
+    const bool owner = wn == c;
 #ifdef AGZ_TIMING_EXPERIMENTS
-    auto stamp = [&](int k) { if (OWNER && wm == 0 && lane == 0 && bid < 16384) g6_trace[bid][4 + 5 * c + k] = g6_now(); };
+    auto stamp = [&](int k) { if (owner && wm == 0 && lane == 0 && bid < 16384) g6_trace[bid][4 + 5 * c + k] = g6_now(); };
 #else
     auto stamp = [&](int) {};
 #endif
     __syncthreads();                                // the K loop / the previous chunk has left the buffers
     stamp(0);
-    if (res) {
+    if (HASRES) {
       // instruction i fills points 8 i .. 8 i + 7: lane = (point, unit u) fetches channel group u ^ ((X >> 1) & 7)
       for (int i = wave; i < WT * 9 / 8; i += 4) {
         const int Xp = 8 * i + (lane >> 3), un = lane & 7;
@@ -390,48 +411,35 @@ __global__ __launch_bounds__(256, 2) void k_wino_gemm6(
       __syncthreads();                              // the residual tile has landed, for every wave
     }
     stamp(1);
-    if constexpr (OWNER) {
+    if (owner) {
       // phase 1.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-      auto rows = [&](auto with_res) {
 #pragma unroll
-        for (int e0 = 0; e0 < 16; e0 += 4) {          // four tile rows at a time: 36 LDS reads behind one wait
-          float* p0[4];
-          float rr[4][9];
+      for (int e0 = 0; e0 < 16; e0 += 4) {          // four tile rows at a time: 36 LDS reads behind one wait
+#ifdef AGZ_TIMING_EXPERIMENTS
+        if (c == 0 && wm == 0 && lane == 0 && bid < 16384) g6_trace[bid][12 + e0 / 4] = g6_now();
+#endif
+        float* p0[4];
+        float rr[4][9];
 #pragma unroll
-          for (int ee = 0; ee < 4; ++ee) {
-            const int e = e0 + ee, row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-            p0[ee] = img + g6_img_off(row, col);      // output k at p0 + k * 64 * 32 (64 k is a multiple of 16: same swizzle)
+        for (int ee = 0; ee < 4; ++ee) {
+          const int e = e0 + ee, row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          p0[ee] = img + g6_img_off(row, col);      // output k at p0 + k * 64 * 32 (64 k is a multiple of 16: same swizzle)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) rr[ee][k] = decltype(with_res)::value ? p0[ee][k * (WT * G6_CH)] : 0.f;
-          }
-#pragma unroll
-          for (int ee = 0; ee < 4; ++ee)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-              float v = o[k][e0 + ee] * sc + sh + rr[ee][k];
-              if (relu_now) v = fmaxf(v, 0.f);
-              p0[ee][k * (WT * G6_CH)] = v;
-            }
+          for (int k = 0; k < 9; ++k) rr[ee][k] = HASRES ? p0[ee][k * (WT * G6_CH)] : 0.f;
         }
-      };
-      if (res) rows(std::true_type{});
-      else rows(std::false_type{});
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+          for (int k = 0; k < 9; ++k)
+            p0[ee][k * (WT * G6_CH)] = fmaxf(o[k][e0 + ee] * sc + sh + rr[ee][k], relu_lo);
+      }
     }
     __syncthreads();
     stamp(2);
-    if constexpr (OWNER) {
-      // phases 1b and 2 live in a function of their own (not inlined): they want ~250 registers, and inlined here the
-      // allocator finds them by spilling running outputs around the K loops (135 scratch reloads in phase 1, 18 us)
+    if (owner) {
       g6_emit<MODE>(img, ptab, y, vnext, tb, cb, c, wm, lane, RPB, Mt, TT, T, N);
       stamp(4);
     }
-  };
-  if (wn == 0) {
-    chunk(0, std::true_type{});
-    chunk(1, std::false_type{});
-  } else {
-    chunk(0, std::false_type{});
-    chunk(1, std::true_type{});
   }
 #ifdef AGZ_TIMING_EXPERIMENTS
   if (tid == 128 && bid < 16384) g6_trace[bid][3] = g6_now();
@@ -473,10 +481,11 @@ void launch_wino_gemm6(const float* vimg, const float* uimg, const float* scale,
   const int blocks = (int)(((long)bcap * T * T + rpb - 1) / rpb);
   const int per_xcd = 2 * ((blocks + 3) / 4);   // see the placement comment in k_wino_gemm6
   const dim3 grid(8 * per_xcd), block(256);
+#define G6_LAUNCH(M, S, XX, PAD) hipLaunchKernelGGL((k_wino_gemm6<M, S, XX>), grid, block, PAD, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu)
   if (ns == kWinoStemStages) {                   // the stem: its output is always wanted in HBM (block 0's residual)
     constexpr int S = kWinoStemStages;
-    if (vnext) hipLaunchKernelGGL((k_wino_gemm6<3, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
-    else hipLaunchKernelGGL((k_wino_gemm6<1, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    if (vnext) G6_LAUNCH(3, S, 0, 0);
+    else G6_LAUNCH(1, S, 0, 0);
     return;
   }
 #ifdef AGZ_TIMING_EXPERIMENTS
@@ -484,7 +493,8 @@ void launch_wino_gemm6(const float* vimg, const float* uimg, const float* scale,
   static int traced = 0;
   static const int pad = getenv("AGZ_WINO_ONE") ? 20000 : 0;      // dynamic LDS on top: one workgroup per CU
   if (getenv("AGZ_WINO_TRACE") && y && vnext && res && ++traced == 3) {      // the third steady-state layer launch of the process
-    hipLaunchKernelGGL((k_wino_gemm6<3, WNS>), grid, block, pad, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    if (xp == 33) G6_LAUNCH(7, WNS, 33, pad);
+    else G6_LAUNCH(7, WNS, 0, pad);
     (void)hipStreamSynchronize(s);
     static unsigned long long host[16384][16];
     (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g6_trace), sizeof(host));
@@ -495,18 +505,18 @@ void launch_wino_gemm6(const float* vimg, const float* uimg, const float* scale,
     return;
   }
   if (xp && y && vnext && res) {
-    auto kern = xp == 1 ? k_wino_gemm6<3, WNS, 1> : xp == 4 ? k_wino_gemm6<3, WNS, 4> : xp == 5 ? k_wino_gemm6<3, WNS, 5>
-              : xp == 11 ? k_wino_gemm6<1, WNS, 0> : xp == 12 ? k_wino_gemm6<2, WNS, 0> : k_wino_gemm6<3, WNS, 0>;
-    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, xp == 12 ? nullptr : res, y, vnext, d_count, N, T, relu);
+    if (xp == 1) G6_LAUNCH(7, WNS, 1, 0);
+    else if (xp == 4) G6_LAUNCH(7, WNS, 4, 0);
+    else if (xp == 5) G6_LAUNCH(7, WNS, 5, 0);
+    else if (xp == 33) G6_LAUNCH(7, WNS, 33, 0);
+    else G6_LAUNCH(7, WNS, 0, 0);
     return;
   }
 #endif
-  if (y && vnext)
-    hipLaunchKernelGGL((k_wino_gemm6<3, WNS>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
-  else if (vnext)
-    hipLaunchKernelGGL((k_wino_gemm6<2, WNS>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
-  else
-    hipLaunchKernelGGL((k_wino_gemm6<1, WNS>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+  if (y && vnext) { if (res) G6_LAUNCH(7, WNS, 0, 0); else G6_LAUNCH(3, WNS, 0, 0); }
+  else if (vnext) { if (res) G6_LAUNCH(6, WNS, 0, 0); else G6_LAUNCH(2, WNS, 0, 0); }
+  else { if (res) G6_LAUNCH(5, WNS, 0, 0); else G6_LAUNCH(1, WNS, 0, 0); }
+#undef G6_LAUNCH
 }
 
 }  // namespace agz
