@@ -537,6 +537,31 @@ function allgather_records!(e::Engine, comm::Ptr{Cvoid} = C_NULL)
   check(e, ccall((:agz_records_clear, libagz), Int32, (Ptr{Cvoid},), e.handle))
   added[]
 end
+# The same exchange with the bytes carried by the HOST's communication library (MPI.jl, Distributed): `allgather` is any
+# function that takes this rank's Vector and returns the concatenation of every rank's, rank order.  Everything but the
+# two collectives is libagz: what this rank announces, the count check / chunk stride (agz_gather_plan: the function
+# agz_allgather_records itself calls), the packed export, device-side indexing and compaction into the arena.
+# A rank whose pack step fails still joins the count collective with {-1, status}: every rank errors together.
+function allgather_records_hosted!(e::Engine, world::Integer, allgather::Function)
+  nb = Ref{Int64}(0)
+  st = ccall((:agz_records_packed_size, libagz), Int32, (Ptr{Cvoid}, Ref{Int64}), e.handle, nb)
+  mine = st == AGZ_OK ? Int64[ccall((:agz_records_count, libagz), Int64, (Ptr{Cvoid},), e.handle), nb[]] : Int64[-1, st]
+  counts = allgather(mine)::Vector{Int64}                                        # 2 x Int64 per rank
+  stride = Ref{Int64}(0); total = Ref{Int64}(0)
+  pst = ccall((:agz_gather_plan, libagz), Int32, (Ptr{Int64}, Int32, Ref{Int64}, Ref{Int64}), counts, world, stride, total)
+  st == AGZ_OK || check(e, st)
+  pst == AGZ_OK || error("libagz status $pst: " * unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), C_NULL)))
+  total[] == 0 && return 0
+  send = zeros(UInt8, stride[])
+  check(e, ccall((:agz_records_export_packed, libagz), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64, Int32), e.handle, send, mine[2], 0))
+  recv = allgather(send)::Vector{UInt8}                                          # world x stride bytes
+  added = Ref{Int64}(0)
+  check(e, ccall((:agz_replay_ingest_gathered, libagz), Int32,
+                 (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32, Int64, Ptr{Int64}, Ref{Int64}),
+                 e.handle, recv, 0, world, stride[], counts, added))
+  check(e, ccall((:agz_records_clear, libagz), Int32, (Ptr{Cvoid},), e.handle))
+  added[]
+end
 broadcast_weights!(e::Engine, comm::Ptr{Cvoid}, root::Integer = 0) =
   check(e, ccall((:agz_broadcast_weights, libagz), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Int64}), e.handle, comm, root, C_NULL))
 

@@ -135,3 +135,124 @@ def test_two_rank_gloo_weight_broadcast():
     want = {str(k): v.tolist() for k, v in StubWeights(seed=11).w.items()}      # rank 1's parameters
     assert got[0][1] == want and got[1][1] == want
     assert got[0][0] == got[1][0] == sum(len(v) for v in want.values())
+
+
+# ---- Engine.allgather_records_hosted (the host-carried exchange) over a stub of the C ABI --------------------------------
+class StubAbi:
+    """The five entry points Engine.allgather_records_hosted calls, over numpy: `records` is this rank's packed export.
+    agz_gather_plan is the REAL library's (pure host code); everything else is a stand-in for an engine on a GPU."""
+
+    def __init__(self, packed, nrec, fail_status=0):
+        import alphago_jl_amd as ag_
+        self.real = ag_.load()
+        self.packed, self.nrec, self.fail = np.ascontiguousarray(packed, np.uint8), nrec, fail_status
+        self.ingested = None
+
+    def agz_records_packed_size(self, h, out):
+        if self.fail:
+            return self.fail
+        out._obj.value = self.packed.size
+        return 0
+
+    def agz_records_count(self, h):
+        return self.nrec
+
+    def agz_gather_plan(self, *a):
+        return self.real.agz_gather_plan(*a)
+
+    def agz_last_error(self, h):
+        return self.real.agz_last_error(None) if h is None else b"stub engine error"
+
+    def agz_records_export_packed(self, h, dst, nbytes, is_device):
+        raise AssertionError("replaced per test")
+
+    def agz_replay_ingest_gathered(self, h, buf, is_device, world, stride, counts, added):
+        import ctypes as C
+        n = world * stride
+        raw = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+        cnt = np.ctypeslib.as_array(counts, shape=(2 * world,)).copy()
+        self.ingested = (raw, int(stride), cnt)
+        added._obj.value = int(cnt[0::2].sum())
+        return 0
+
+
+def hosted_worker(rank, world, port, sizes, fail_rank, q):
+    import ctypes as C
+
+    import torch
+
+    import alphago_jl_amd as ag_
+    from alphago_jl_amd.engine import Engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nrec, nbytes = sizes[rank]
+    packed = (np.arange(nbytes, dtype=np.int64) * 7 + rank * 31).astype(np.uint8)
+    eng = Engine.__new__(Engine)                       # no engine behind it: the protocol logic only
+    eng.L = StubAbi(packed, nrec, ag_._lib.HIP_ERROR if rank == fail_rank else 0)
+    eng.h, eng.cfg = None, type("Cfg", (), {"device": 0})()
+
+    # the export writes into a CUDA tensor in the real method; on this GPU-less host route it through a CPU tensor
+    real_zeros = torch.zeros
+
+    def zeros_cpu(*a, **kw):
+        kw["device"] = "cpu"
+        return real_zeros(*a, **kw)
+
+    torch.zeros = zeros_cpu
+
+    def export(h, dst, nb, is_device):
+        C.memmove(dst, packed.ctypes.data, int(nb))
+        return 0
+
+    eng.L.agz_records_export_packed = export
+    out = {"rank": rank}
+    try:
+        out["added"] = eng.allgather_records_hosted()
+        raw, stride, cnt = eng.L.ingested if eng.L.ingested else (None, 0, None)
+        out["stride"], out["counts"] = stride, None if cnt is None else cnt.tolist()
+        if raw is not None:
+            out["chunks"] = [raw[r * stride: r * stride + sizes[r][1]].tolist() for r in range(world)]
+    except ag_.AgzError as ex:
+        out["error"] = (int(ex.status), str(ex))
+    torch.zeros = real_zeros
+    dist.barrier()
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def run_hosted(sizes, fail_rank=-1):
+    world = len(sizes)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=hosted_worker, args=(r, world, port, sizes, fail_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        o = q.get(timeout=300)
+        got[o["rank"]] = o
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+def test_hosted_exchange_protocol_two_gloo_ranks():
+    """counts -> agz_gather_plan -> padded payload -> ingest, as Engine.allgather_records_hosted runs it (the GPU version of
+    this test, with real engines, is tests/test_gpu_multirank.py): unequal ranks, stride = the largest padded to 256"""
+    sizes = [(3, 3 * 32 + 1000), (1, 40)]
+    got = run_hosted(sizes)
+    for r in (0, 1):
+        assert got[r]["added"] == 4 and got[r]["stride"] == 1280 and got[r]["counts"] == [3, 1096, 1, 40]
+    want = [((np.arange(nb, dtype=np.int64) * 7 + r * 31).astype(np.uint8)).tolist() for r, (_, nb) in enumerate(sizes)]
+    assert got[0]["chunks"] == want and got[1]["chunks"] == want
+
+
+def test_hosted_exchange_of_nothing_and_failure_sentinel():
+    got = run_hosted([(0, 0), (0, 0)])
+    assert got[0]["added"] == got[1]["added"] == 0
+    got = run_hosted([(2, 128), (1, 64)], fail_rank=0)
+    assert got[0]["error"][0] == ag._lib.HIP_ERROR                       # the failing rank reports its own failure
+    assert got[1]["error"][0] == ag._lib.RCCL_ERROR and "rank 0 failed before the exchange" in got[1]["error"][1]
