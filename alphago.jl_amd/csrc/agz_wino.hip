@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   //   2   next layer's input transform V = B^T d B from img -> HBM stage images   (MODE & 2)
   __syncthreads();
   float* img = lds;
-  static_assert(IMG_FLOATS <= 3 * STAGE, "tile image exceeds the stage buffers");
+  static_assert(IMG_FLOATS + WC <= 3 * STAGE, "tile image (+ the block of zeros phase 2 reads for off-board points) exceeds the stage buffers");
+  if (tid < WC) img[IMG_FLOATS + tid] = 0.f;        // (published by the barrier behind phase 1)
   const bool pass1b = (MODE & 1) != 0;
   if (res) {
     // instruction i fills points 4i .. 4i+3: lane = (point, unit u) fetches channel group u ^ (X & 15)
@@ -577,23 +578,24 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     // Dense blocks (19x19): only the tiles whose neighbours are rows of this block (wino_tile_fused); the others, and
     // the dead rows, are k_wino_in<FIXUP>'s.
     const bool emit = wino_whole_boards(T) || (live && wino_tile_fused(T, row, ti, tj));
-    int poff[25];
+    // Patch point (u, v) of tile (ti, tj) is board point (3 ti - 1 + u, 3 tj - 1 + v): output k = (ku, kv) of the tile
+    // du rows of tiles / dv tiles further on, with (du, ku) = (-1, 2), (0, 0), (0, 1), (0, 2), (1, 0) for u = 0..4 -- written
+    // out, because the compiler cannot see that and spends fifty run-time divisions by 3 on `pi / 3`, `pi % 3`.  A point
+    // off the board (or a lane that emits nothing) reads a block of zeros behind the image instead of being masked out:
+    // no exec juggling around 25 (50) conditional loads per task.
+    int pbase[25], pxm[25];            // float offset of point X's row in img, and its swizzle X & 15
 #pragma unroll
     for (int u = 0; u < 5; ++u)
 #pragma unroll
       for (int v = 0; v < 5; ++v) {
+        const int du = u == 0 ? -1 : (u == 4 ? 1 : 0), ku = u == 0 ? 2 : (u == 4 ? 0 : u - 1);
+        const int dv = v == 0 ? -1 : (v == 4 ? 1 : 0), kv = v == 0 ? 2 : (v == 4 ? 0 : v - 1);
         const int pi = 3 * ti - 1 + u, pj = 3 * tj - 1 + v;
         const bool ok = live && emit && pi >= 0 && pi < N && pj >= 0 && pj < N;
-        // the point lives in tile (pi / 3, pj / 3) of the same board = row + (pi / 3 - ti) T + (pj / 3 - tj) of this
-        // block, output k = (pi % 3) * 3 + pj % 3
-        poff[u * 5 + v] = ok ? ((pi % 3) * 3 + pj % 3) * WT + row + (pi / 3 - ti) * T + (pj / 3 - tj) : -1;      // = X
+        const int Xq = (ku * 3 + kv) * WT + row + du * T + dv;
+        pbase[u * 5 + v] = ok ? Xq * WC : IMG_FLOATS;
+        pxm[u * 5 + v] = ok ? (Xq & 15) : 0;
       }
-    int pbase[25], pxm[25];            // float offset of point X's row in img, and its swizzle X & 15
-#pragma unroll
-    for (int q = 0; q < 25; ++q) {
-      pbase[q] = poff[q] * WC;
-      pxm[q] = poff[q] & 15;
-    }
     // a V image row is one plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1 (wino_v_off)
     const int sw2 = 2 * ((row >> 4) & 1);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -602,16 +604,14 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       f32x4 d[25];
 #pragma unroll
       for (int q = 0; q < 25; ++q) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if constexpr (SPLIT) {
-          d[q] = poff[q] >= 0 ? *reinterpret_cast<const f32x4*>(img + pbase[q] + 4 * (sl ^ pxm[q])) : z;
+          d[q] = *reinterpret_cast<const f32x4*>(img + pbase[q] + 4 * (sl ^ pxm[q]));
         } else {
           // the lane's two channel pairs in the order its V row wants them (rows with bit 4 set store pair 1 first): two
           // 8-byte reads at lane-dependent halves of the unit instead of 104 selects per task on the way out
           const float* u = img + pbase[q] + 4 * (sl ^ pxm[q]);
-          const f32x2 zz = {0.f, 0.f};
-          const f32x2 a = poff[q] >= 0 ? *reinterpret_cast<const f32x2*>(u + sw2) : zz;
-          const f32x2 b = poff[q] >= 0 ? *reinterpret_cast<const f32x2*>(u + (2 - sw2)) : zz;
+          const f32x2 a = *reinterpret_cast<const f32x2*>(u + sw2);
+          const f32x2 b = *reinterpret_cast<const f32x2*>(u + (2 - sw2));
           d[q] = (f32x4){a[0], a[1], b[0], b[1]};
         }
       }
