@@ -32,6 +32,7 @@
 #include "agz_nn.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -240,6 +241,8 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
 // front of them, serialising load and compute (measured: 38 % MFMA utilisation).  An asm statement
 // is outside its vmcnt book-keeping, so the wait is placed by hand, once per stage, right before
 // the barrier that hands the buffer over.
+// (M0 is saved and restored around every piece: the compiler keeps M0 reserved and does not accept it as a clobber.
+// Dropping the two s_mov measured -1.5 % per layer in round 2 and +-0 in a round-3 same-box A/B; not worth the risk.)
 __device__ __forceinline__ void glds16(const float* g, unsigned lds_byte_addr) {
   unsigned keep;
   lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);   // make the SGPR operand provable
@@ -287,6 +290,13 @@ __device__ __forceinline__ void glds16s(const float* gbase_uniform, unsigned lan
 // one channel group for all its elements -- the epilogue is VALU-issue bound (a lone wave per SIMD), address
 // arithmetic per access is what it can least afford.
 constexpr int IMG_FLOATS = WT * 9 * WC;          // 147,456 B
+#ifdef AGZ_TIMING_EXPERIMENTS
+// per workgroup: {hw id | xcc id << 32, start, K loop done, phase 1 done, phase 1b done, end} on the 100 MHz wall clock
+__device__ unsigned long long g4_trace[16384][8];
+#define G4_STAMP(k) do { if (tid == 0 && blockIdx.x < 16384) g4_trace[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define G4_STAMP(k) do { } while (0)
+#endif
 
 // MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
 // X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
@@ -317,6 +327,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
+#ifdef AGZ_TIMING_EXPERIMENTS
+  if (tid == 0 && blockIdx.x < 16384) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g4_trace[blockIdx.x][0] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
+  G4_STAMP(1);
+#endif
   const float* asrc = vimg + (long)tb * NS * A_STAGE;
   const float* bsrc = uimg + (long)cb * NS * B_STAGE;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0];
@@ -406,13 +425,43 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     }
   };
 
-  asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  // (projection experiments, DESIGN 4e: X = 8 moves 11 instead of 13 pieces per wave and stage -- the DMA volume of a
+  // half-transformed A operand; X = 9 adds the 50 packed operations per stage its second pass would cost the wave;
+  // X = 10 stores 15 of the 25 planes in phase 2 after one transform pass; X = 7 all three.  Results are WRONG.)
+  constexpr int PW = (X == 7 || X == 8) ? 11 : 13;
+  auto wait_stage = [&]() {
+    if constexpr (PW == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  };
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t dum0 = {1.f, 2.f}, dum1 = {3.f, 4.f}, dumc = {0.5f, 0.25f};
+  wait_stage();
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < LA; ++k) load(lds, k, ra[k], rb[k]);
 
   // One stage.  MORE: stage st+2 exists and is fetched during this stage; NEXT: stage st+1 exists.  Both are
   // compile-time so that the 62 full stages run a branch-free body (the two tail stages are separate code).
+  // Residual prefetch.  The tile image of the epilogue lies over the three stage buffers; the buffer of stage NS-3 is
+  // dead during stage NS-2 and that of stage NS-2 during stage NS-1, when the K loop has no pieces of its own left to
+  // fetch: the residual's pieces for those two thirds of the image (instruction i = wave + 4 n fills image bytes
+  // 1024 i ..: n 13..25 lie in buffer 1, n 26..35 in buffer 2, NS % 3 == 1 makes those the dead ones) go out in the DMA
+  // slots of the last two stages instead of behind the loop, where the inverse transform (1.5 us) is too short to cover
+  // 144 KB arriving from HBM at 16 B/clk/CU (3.9 us).  n 0..12 (buffer 0, the last stage's) follow behind the loop.
+  static_assert(NS % 3 == 1 || NS == kWinoStemStages, "residual prefetch assumes the last stage is read from buffer 0");
+#ifdef AGZ_X_RESPF         // measured: phase 1 -2.9 us, phase 2 +2.1 us (the epilogues stay in lockstep), layer +-0
+  constexpr bool RESPF = NS % 3 == 1;
+#else
+  constexpr bool RESPF = false;
+#endif
+  auto rdma = [&](int n) {
+    // instruction i fills points 4i .. 4i+3: lane = (point, unit u) fetches channel group u ^ (X & 15)
+    const int i = wave + 4 * n;
+    const int Xp = 4 * i + (lane >> 4), u = lane & 15;
+    const int off = ptab[Xp];
+    const float* g = res + (off >= 0 ? off + 4 * (u ^ (Xp & 15)) : 0);      // dead points: any valid address
+    glds16(g, lds0 + (unsigned)(i * 256) * 4u);
+  };
   int buf = 0;
   auto stage = [&](int st, auto more_c, auto next_c) {
     constexpr bool more = decltype(more_c)::value, next = decltype(next_c)::value;
@@ -426,7 +475,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       if (t == WXI && next) {
         // everything this wave owes to stage st+1 has landed (its share of stage st+2, all 13 pieces issued by
         // now, may still be in flight); hipcc adds lgkmcnt(0) in front of the barrier: all reads of stage st are back
-        if (more && X != 4) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        // (stage NS-2 with a residual: the 13 youngest are this stage's residual pieces)
+        if (more && X != 4) wait_stage();
+        else if (!more && RESPF && res && X != 4) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
@@ -435,9 +486,17 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       // one piece per plane slot: in the middle of the stage in the f32 form (vs every other slot: -2 %), at its very
       // top in the split form, whose matrix work is short and whose loop waits for the stream anyway
       constexpr int D0 = SPLIT ? 0 : 6;
-      if (more && k >= D0 && k < D0 + 13) {
+      if (more && k >= D0 && k < D0 + PW) {
         __builtin_amdgcn_sched_barrier(0);
         if (X != 4) dma(st + 2, dbuf, k - D0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (X == 7 || X == 9) {
+        asm volatile("v_pk_fma_f32 %0, %0, %2, %0\n\tv_pk_fma_f32 %1, %1, %2, %1" : "+v"(dum0), "+v"(dum1) : "v"(dumc));
+      }
+      if (!more && RESPF && k >= D0 && k < D0 + (next ? 13 : 10)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (res) rdma((next ? 13 : 26) + k - D0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (X != 5) mma(k, ra[k % RING], rb[k % RING]);
@@ -459,6 +518,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 #pragma unroll
     for (int k = 0; k < WXI; ++k) keep += acc[k][0] + acc[k][15];
     if (keep == 123.456f) y[0] = keep;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // residual pieces may still be landing in LDS
     return;
   }
 
@@ -470,18 +530,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   //   1b  img -> y: 256-byte runs per output point, 16 B per lane; only where y is wanted (MODE & 1)
   //   2   next layer's input transform V = B^T d B from img -> HBM stage images   (MODE & 2)
   __syncthreads();
+  G4_STAMP(2);
   float* img = lds;
   static_assert(IMG_FLOATS + WC <= 3 * STAGE, "tile image (+ the block of zeros phase 2 reads for off-board points) exceeds the stage buffers");
   if (tid < WC) img[IMG_FLOATS + tid] = 0.f;        // (published by the barrier behind phase 1)
   const bool pass1b = (MODE & 1) != 0;
   if (res) {
-    // instruction i fills points 4i .. 4i+3: lane = (point, unit u) fetches channel group u ^ (X & 15)
-    for (int i = wave; i < WT * 9 / 4; i += 4) {
-      const int Xp = 4 * i + (lane >> 4), u = lane & 15;
-      const int off = ptab[Xp];
-      const float* g = res + (off >= 0 ? off + 4 * (u ^ (Xp & 15)) : 0);      // dead points: any valid address
-      glds16(g, lds0 + (unsigned)(i * 256) * 4u);
-    }
+    static_assert(WT * 9 / 4 == 4 * 36, "36 residual pieces per wave");
+#pragma unroll
+    for (int n = 0; n < (RESPF ? 13 : 36); ++n) rdma(n);
   }
   {
     // phase 1.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -509,10 +566,17 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
         o[i * 3 + 2] = ((tmp[i][1] + tmp[i][2]) + 4.f * tmp[i][3]) + tmp[i][4];
       }
     }
+    // hipcc would otherwise sink the whole transform below the wait and the barrier (it is register arithmetic, nothing
+    // orders it against them) and the wave would sit out the residual's flight before starting on it
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if (RESPF) asm volatile("" : "+v"(o[k]));
+    G4_STAMP(6);
     if (res) {                                    // the residual tile has landed, for every wave
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    G4_STAMP(7);
     // img = (residual +) value.  ds_add_f32 would do the sum in one instruction, but LDS float atomics run at a
     // fraction of the ds_write rate (+0.75 ms per layer measured): read the nine residuals of a row, add, write
     auto rows = [&](auto with_res) {
@@ -541,6 +605,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     else rows(std::false_type{});
   }
   __syncthreads();
+  G4_STAMP(3);
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   if (pass1b) {
     // phase 1b: element = (row, k, 4 channels); 16 consecutive lanes cover the 256 contiguous bytes of one point
@@ -563,6 +628,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
         if ((MODE & 1) && offs[i0 + j] >= 0) *reinterpret_cast<f32x4*>(y + offs[i0 + j] + cg4) = v[j];
     }
   }
+  G4_STAMP(4);
   if (!(MODE & 2) || X == 2) return;
 
   // ---- phase 2: the next layer's input transform for this workgroup's 64 channels (= stages 16 cb .. 16 cb + 15
@@ -642,13 +708,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
           f32x2 r[5];
-          bt5p(tx[i * 5 + 0], tx[i * 5 + 1], tx[i * 5 + 2], tx[i * 5 + 3], tx[i * 5 + 4], r);
+          if (X == 7 || X == 10) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) r[j] = tx[i * 5 + j];
+          } else {
+            bt5p(tx[i * 5 + 0], tx[i * 5 + 1], tx[i * 5 + 2], tx[i * 5 + 3], tx[i * 5 + 4], r);
+          }
 #pragma unroll
           for (int j = 0; j < 5; ++j) vv[i * 5 + j][h] = r[j];
         }
       }
 #pragma unroll
-      for (int xi = 0; xi < WXI; ++xi) {              // (the 26th plane slot of an image is padding nobody multiplies with)
+      for (int xi = 0; xi < ((X == 7 || X == 10) ? 15 : WXI); ++xi) {      // (the 26th plane slot of an image is padding nobody multiplies with)
         const f32x2 p0 = vv[xi][0], p1 = vv[xi][1];
         f32x4 v4;
         if constexpr (SPLIT) {
@@ -671,6 +742,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       }
     }
   }
+  G4_STAMP(5);
 }
 
 // ------------------------------------------------------------------ host side
@@ -778,6 +850,18 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   }
 #ifdef AGZ_TIMING_EXPERIMENTS
   static const int xp = getenv("AGZ_WINO_X") ? atoi(getenv("AGZ_WINO_X")) : 0;
+  static int traced = 0;
+  if (getenv("AGZ_WINO_TRACE") && y && vnext && res && !split && ++traced == 3) {      // third steady-state layer launch
+    hipLaunchKernelGGL((k_wino_gemm4<3>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[16384][8];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_trace), sizeof(host));
+    if (FILE* f = fopen(getenv("AGZ_WINO_TRACE"), "wb")) {
+      fwrite(host, 1, sizeof(host), f);
+      fclose(f);
+    }
+    return;
+  }
   if (xp && y && vnext && res && split) {
     auto kern = xp == 1 ? k_wino_gemm4<3, 1, true> : xp == 2 ? k_wino_gemm4<3, 2, true> : xp == 3 ? k_wino_gemm4<3, 3, true>
               : xp == 5 ? k_wino_gemm4<3, 5, true> : k_wino_gemm4<3, 0, true>;
@@ -787,6 +871,7 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   if (xp && y && vnext && res && !split) {
     auto kern = xp == 1 ? k_wino_gemm4<3, 1> : xp == 2 ? k_wino_gemm4<3, 2> : xp == 3 ? k_wino_gemm4<3, 3>
               : xp == 4 ? k_wino_gemm4<3, 4> : xp == 5 ? k_wino_gemm4<3, 5> : xp == 6 ? k_wino_gemm4<3, 6>
+              : xp == 7 ? k_wino_gemm4<3, 7> : xp == 8 ? k_wino_gemm4<3, 8> : xp == 9 ? k_wino_gemm4<3, 9> : xp == 10 ? k_wino_gemm4<3, 10>
               : xp == 11 ? k_wino_gemm4<1, 0> : xp == 12 ? k_wino_gemm4<2, 0> : k_wino_gemm4<3, 0>;
     hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, xp == 12 ? nullptr : res, y, vnext, d_count, N, T, relu);
     return;
