@@ -301,7 +301,7 @@ __device__ unsigned long long g4_trace[16384][8];
 // MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
 // X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
 //   1 = K loop only; 2 = no epilogue 2; 3 = epilogue 2 without its global stores; 4 = no DMA after the prologue;
-//   5 = no MFMA; 6 = no LDS operand reads
+//   5 = no MFMA; 6 = no LDS operand reads; 13 / 14 / 15 = every stage's DMA (of both operands / U / V) from the same two (L2-resident) stage images
 // NS: stages of the K loop (input channels / 4): 64, or 8 for the stem
 template <int MODE, int X = 0, bool SPLIT = false, int NS = WNS>
 __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   // address arithmetic in front of every piece cost 8 % of the K loop (2.10 -> 1.95 ms per layer)
   auto dma = [&](int st, int buf, int j) {
     const int c = 13 * wave + j;
-    const float* g = wave < 2 ? asrc + (long)st * A_STAGE + c * 256 : bsrc + (long)st * B_STAGE + (c - 26) * 256;
+    // (timing: every stage from the same two L2-resident stage images: 13 both operands, 14 only U, 15 only V)
+    const int sa = (X == 13 || X == 15) ? (st & 1) : st, sb = (X == 13 || X == 14) ? (st & 1) : st;
+    const float* g = wave < 2 ? asrc + (long)sa * A_STAGE + c * 256 : bsrc + (long)sb * B_STAGE + (c - 26) * 256;
     glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
   };
 
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
       else if (next) load(Ln, t - WXI, ra[t % RING], rb[t % RING]);
       // one piece per plane slot: in the middle of the stage in the f32 form (vs every other slot: -2 %), at its very
       // top in the split form, whose matrix work is short and whose loop waits for the stream anyway
-      constexpr int D0 = SPLIT ? 0 : 6;
+      constexpr int D0 = SPLIT ? 0 : 6;      // (f32, same-box: D0 = 3 and 9 the same, D0 = 0 +1 % per forward)
       if (more && k >= D0 && k < D0 + PW) {
         __builtin_amdgcn_sched_barrier(0);
         if (X != 4) dma(st + 2, dbuf, k - D0);
@@ -871,7 +873,7 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   if (xp && y && vnext && res && !split) {
     auto kern = xp == 1 ? k_wino_gemm4<3, 1> : xp == 2 ? k_wino_gemm4<3, 2> : xp == 3 ? k_wino_gemm4<3, 3>
               : xp == 4 ? k_wino_gemm4<3, 4> : xp == 5 ? k_wino_gemm4<3, 5> : xp == 6 ? k_wino_gemm4<3, 6>
-              : xp == 7 ? k_wino_gemm4<3, 7> : xp == 8 ? k_wino_gemm4<3, 8> : xp == 9 ? k_wino_gemm4<3, 9> : xp == 10 ? k_wino_gemm4<3, 10>
+              : xp == 13 ? k_wino_gemm4<3, 13> : xp == 14 ? k_wino_gemm4<3, 14> : xp == 15 ? k_wino_gemm4<3, 15> : xp == 7 ? k_wino_gemm4<3, 7> : xp == 8 ? k_wino_gemm4<3, 8> : xp == 9 ? k_wino_gemm4<3, 9> : xp == 10 ? k_wino_gemm4<3, 10>
               : xp == 11 ? k_wino_gemm4<1, 0> : xp == 12 ? k_wino_gemm4<2, 0> : k_wino_gemm4<3, 0>;
     hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, xp == 12 ? nullptr : res, y, vnext, d_count, N, T, relu);
     return;
