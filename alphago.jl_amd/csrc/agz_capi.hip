@@ -150,6 +150,9 @@ agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_
 agz_status agz_net_set_winograd(agz_engine* e, int32_t on) {
   return guard(e, [&](agz::Engine& E) { E.net().set_winograd(on != 0); });
 }
+agz_status agz_net_set_tower_persistent(agz_engine* e, int32_t on) {
+  return guard(e, [&](agz::Engine& E) { E.net().set_tower_persistent(on != 0); });
+}
 agz_status agz_net_set_precision(agz_engine* e, int32_t precision) {
   return guard(e, [&](agz::Engine& E) {
     AGZ_REQUIRE(precision == AGZ_PRECISION_F32 || precision == AGZ_PRECISION_F16 || precision == AGZ_PRECISION_F32S,

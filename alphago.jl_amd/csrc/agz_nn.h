@@ -50,6 +50,11 @@ class Net {
   // tower convolution algorithm: Winograd F(3x3,3x3) (default) or the direct implicit GEMM
   void set_winograd(bool on) { winograd_ = on; }
   bool winograd() const { return winograd_; }
+  // the f32 Winograd tower as ONE persistent launch (k_wino_tower) instead of one launch per layer, where it applies
+  // (whole-board tile blocks, 256 CUs with 32 resident workgroups per XCD); same arithmetic, same bits.  Off by
+  // default: it needs 3.7 % fewer cycles and the clock comes down by as much -- same wall time.
+  void set_tower_persistent(bool on) { tower_persistent_ = on; }
+  bool tower_persistent() const { return tower_persistent_; }
   // tower arithmetic: 0 = exact f32 (default), 1 = fp16 operands / f32 accumulate (agz_conv16.hip)
   // 2 = exact-f32 network with the Winograd operands carried as two f16 halves (agz_wino.hip, split form)
   void set_precision(int p) { precision_ = p; dirty_ = dirty_ || p == 1 || p == 2; }
@@ -111,7 +116,14 @@ class Net {
   bool packed16_ = false;
   DevBuf<uint16_t> d_wi16_;               // fp16 tower weights as padded LDS tile images [layer][stage 72][256][40]
   DevBuf<uint16_t> d_ha_, d_hb_, d_ht_;   // fp16 tower activations [rows][256]
+  // persistent tower launch
+  bool tower_persistent_ = false;
+  DevBuf<int> d_tower_sched_;
+  DevBuf<char> d_tower_layers_;
+  std::vector<char> tower_layers_host_;      // what d_tower_layers_ holds
+  int32_t* tower_err_ = nullptr;             // pinned host: the scheduler's error word of the previous forward
   // profiling
+  std::vector<int> prof_mult_;               // layers behind event pair i (1, or the whole tower for the persistent launch)
   bool prof_on_ = false;
   std::vector<hipEvent_t> prof_ev_;
   std::vector<int> prof_fwd_of_;
@@ -170,6 +182,16 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s,
                       int ns = kWinoStages);
 bool wino_fusable(int N);
+// the tower in one persistent launch (agz_wino.hip: k_wino_tower).  Layer table entry, device side:
+struct WinoTowerLayer {
+  const float *v, *u, *scale, *shift, *res;
+  float *y, *vnext;
+  int mode, relu;      // mode bit 0: write y; bit 1: emit the next layer's V
+};
+size_t wino_tower_sched_ints(int layers, int bcap, int N);
+bool wino_tower_supported(hipStream_t s);
+void launch_wino_tower(const void* d_layers, int layers, int* d_sched, const int* d_count, int bcap, int N, bool split, hipStream_t s);
+constexpr int kWinoTowerErrWord = 8;         // int offset of the scheduler's error word in d_sched
 // split-operand form (AGZ_PRECISION_F32S): weights as (hi, lo) halves of 2^10 u; 1 / (operand scales) for the epilogue
 void wino_pack_weights_split(const ConvHost& c, float* out, int ns = kWinoStages);
 float wino_split_descale();

@@ -659,6 +659,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
     launch();
     if (p) {
       (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
+      prof_mult_[prof_n_] = 1;
       prof_fwd_of_[prof_n_++] = prof_fwd_;
     }
   };
@@ -710,6 +711,44 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
                          d_shift_.p, nullptr, a, vcur, d_count, bcap, N_, 1, split, stream_, kWinoStemStages);
         if (dense) launch_wino_in(a, vcur, d_count, bcap, N_, split, stream_, kWinoStages, true);
       }
+      const bool persistent = tower_persistent_ && !dense && stem_wino && wino_tower_supported(stream_);
+      if (persistent) {
+        // the same layers as the loop below, as a table for ONE persistent launch (k_wino_tower)
+        AGZ_REQUIRE(!tower_err_ || *tower_err_ == 0, AGZ_HIP_ERROR,
+                    "the persistent tower kernel of the previous forward gave up waiting for a tile block (scheduler error word set)");
+        const int nl = 2 * tower_;
+        std::vector<WinoTowerLayer> tab(nl);
+        float *pa = a, *pb = b, *vc = vcur, *vn = vnxt;
+        for (int blk = 0; blk < tower_; ++blk) {
+          const int l1 = 2 * blk, l2 = 2 * blk + 1;
+          const bool last = blk + 1 == tower_;
+          tab[l1] = {vc, usrc + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, nullptr, vn, 2, 1};
+          tab[l2] = {vn, usrc + uper * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, pa, pb, last ? nullptr : vc, last ? 1 : 3, 1};
+          std::swap(pa, pb);
+        }
+        const size_t tbytes = sizeof(WinoTowerLayer) * tab.size();
+        if (tower_layers_host_.size() != tbytes || std::memcmp(tower_layers_host_.data(), tab.data(), tbytes) != 0) {
+          AGZ_HIP(hipStreamSynchronize(stream_));      // (rare: first forward, or the workspace moved)
+          tower_layers_host_.assign((const char*)tab.data(), (const char*)tab.data() + tbytes);
+          d_tower_layers_.ensure(tbytes);
+          AGZ_HIP(hipMemcpy(d_tower_layers_.p, tower_layers_host_.data(), tbytes, hipMemcpyHostToDevice));
+        }
+        d_tower_sched_.ensure(wino_tower_sched_ints(nl, bcap, N_));
+        if (!tower_err_) {
+          AGZ_HIP(hipHostMalloc((void**)&tower_err_, sizeof(int32_t), hipHostMallocDefault));
+          *tower_err_ = 0;
+        }
+        const bool p = prof_on_ && prof_n_ < kProfMax;
+        if (p) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+        launch_wino_tower(d_tower_layers_.p, nl, d_tower_sched_.p, d_count, bcap, N_, split, stream_);
+        if (p) {
+          (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
+          prof_mult_[prof_n_] = nl;
+          prof_fwd_of_[prof_n_++] = prof_fwd_;
+        }
+        (void)hipMemcpyAsync(tower_err_, d_tower_sched_.p + kWinoTowerErrWord, sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
+        if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
+      } else
       for (int blk = 0; blk < tower_; ++blk) {     // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32
         const int l1 = 2 * blk, l2 = 2 * blk + 1;
         const bool last = blk + 1 == tower_;
@@ -754,6 +793,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
 Net::~Net() {
   for (auto e : prof_ev_) (void)hipEventDestroy(e);
   if (prof_counts_) (void)hipHostFree(prof_counts_);
+  if (tower_err_) (void)hipHostFree(tower_err_);
 }
 
 void Net::profile_enable(bool on) {
@@ -761,6 +801,7 @@ void Net::profile_enable(bool on) {
     prof_ev_.resize(2 * kProfMax);
     for (auto& e : prof_ev_) AGZ_HIP(hipEventCreate(&e));
     prof_fwd_of_.assign(kProfMax, 0);
+    prof_mult_.assign(kProfMax, 1);
     AGZ_HIP(hipHostMalloc((void**)&prof_counts_, sizeof(int32_t) * kProfMax, hipHostMallocDefault));
   }
   prof_on_ = on;
@@ -771,16 +812,18 @@ void Net::profile_enable(bool on) {
 void Net::profile_read(double* total_ms, double* total_flop, int64_t* launches) {
   AGZ_HIP(hipStreamSynchronize(stream_));
   double ms = 0.0, fl = 0.0;
+  int64_t n = 0;
   for (int i = 0; i < prof_n_; ++i) {
     float t = 0.f;
     AGZ_HIP(hipEventElapsedTime(&t, prof_ev_[2 * i], prof_ev_[2 * i + 1]));
     ms += t;
     const int f = prof_fwd_of_[i];
-    fl += conv_flops_per_launch(f < kProfMax ? prof_counts_[f] : 0);
+    fl += prof_mult_[i] * conv_flops_per_launch(f < kProfMax ? prof_counts_[f] : 0);
+    n += prof_mult_[i];         // the persistent tower launch counts as its layers: `launches` stays "tower layers timed"
   }
   *total_ms = ms;
   *total_flop = fl;
-  *launches = prof_n_;
+  *launches = n;
 }
 
 void Net::launch_tower_conv_once(const int* d_count, int bcap) {

@@ -261,6 +261,23 @@ __device__ __forceinline__ void glds16s(const float* gbase_uniform, unsigned lan
                : "=&s"(keep) : "v"(lane_byte_off), "s"(gbase_uniform), "s"(lds_byte_addr) : "memory");
 }
 
+// the same with the sc1 bit: served by L2, never by this CU's vector L1 (data another CU of the XCD has just written)
+__device__ __forceinline__ void glds16_l2(const float* g, unsigned lds_byte_addr) {
+  unsigned keep;
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds_byte_addr)
+      : "memory");
+}
+__device__ __forceinline__ void glds16s_l2(const float* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_addr) {
+  unsigned keep;
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_byte_off), "s"(gbase_uniform), "s"(lds_byte_addr) : "memory");
+}
+
 // ------------------------------------------------------------------ GEMM + output transform + next input transform
 //
 // k_wino_gemm4: the same 64 tiles x 64 couts x 25 planes workgroup tile, held by FOUR waves -- one per SIMD,
@@ -303,27 +320,18 @@ __device__ unsigned long long g4_trace[16384][8];
 //   1 = K loop only; 2 = no epilogue 2; 3 = epilogue 2 without its global stores; 4 = no DMA after the prologue;
 //   5 = no MFMA; 6 = no LDS operand reads; 13 / 14 / 15 = every stage's DMA (of both operands / U / V) from the same two (L2-resident) stage images
 // NS: stages of the K loop (input channels / 4): 64, or 8 for the stem
-template <int MODE, int X = 0, bool SPLIT = false, int NS = WNS>
-__global__ __launch_bounds__(256, 1) void k_wino_gemm4(
-    const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
-  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
-  __shared__ int ptab[WT * 9];     // element offset of output point X in y / res, or -1 (off the board / dead row)
+// COH: every LDS-DMA load carries sc1 (served by L2, not by this CU's L1): the persistent tower kernel below reads what
+// other workgroups of its XCD wrote earlier in the same launch.  Costs nothing (same-box A/B +-0).
+// One workgroup's work: tile block tb x cout block cb of one layer.  lds / ptab: the workgroup's shared memory.
+template <int X, bool SPLIT, int NS, bool COH>
+__device__ __forceinline__ void wino_wg(
+    float* __restrict__ lds, int* __restrict__ ptab, const float* __restrict__ vimg, const float* __restrict__ uimg,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+    float* __restrict__ vnext, const long Mt, const int N, const int T, const int relu, const int tb, const int cb, const int MODE,
+    const int tid) {
   const int P = N * N, TT = T * T;
   const int RPB = wino_rows_per_block(T);
-  const long Mt = (long)(*d_count) * TT;
-  // workgroup -> (tile block, cout block): block b runs on XCD b % 8.  The four cout blocks of a tile block are four
-  // CONSECUTIVE workgroups of one XCD, so its V slab (1.7 MB) comes out of HBM once and is served to the other three from
-  // that XCD's L2.  Rounds 1-2 split a tile block over an XCD pair (two cout blocks each, so that the 3.3 MB of U an XCD
-  // needs stay in its 4 MB L2): V then crossed HBM twice -- 4.0 of the layer's 7.2 GB.  With all of U (6.5 MB) wanted by
-  // every XCD the U misses go to the Infinity Cache instead; measured -0.65 % per forward (A/B, same box) and V read once.
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, jb = bid >> 3;
-  const int cb = jb & 3;
-  const int tb = xcd + 8 * (jb >> 2);
-  if ((long)tb * RPB >= Mt) return;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -348,7 +356,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     // (timing: every stage from the same two L2-resident stage images: 13 both operands, 14 only U, 15 only V)
     const int sa = (X == 13 || X == 15) ? (st & 1) : st, sb = (X == 13 || X == 14) ? (st & 1) : st;
     const float* g = wave < 2 ? asrc + (long)sa * A_STAGE + c * 256 : bsrc + (long)sb * B_STAGE + (c - 26) * 256;
-    glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
+    if constexpr (COH) glds16s_l2(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
+    else glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
   };
 
   // the first two stages are on their way before anything else: the point table and the 400 accumulator zeros below
@@ -462,7 +471,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const int Xp = 4 * i + (lane >> 4), u = lane & 15;
     const int off = ptab[Xp];
     const float* g = res + (off >= 0 ? off + 4 * (u ^ (Xp & 15)) : 0);      // dead points: any valid address
-    glds16(g, lds0 + (unsigned)(i * 256) * 4u);
+    if constexpr (COH) glds16_l2(g, lds0 + (unsigned)(i * 256) * 4u);
+    else glds16(g, lds0 + (unsigned)(i * 256) * 4u);
   };
   int buf = 0;
   auto stage = [&](int st, auto more_c, auto next_c) {
@@ -747,6 +757,155 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   G4_STAMP(5);
 }
 
+template <int MODE, int X = 0, bool SPLIT = false, int NS = WNS>
+__global__ __launch_bounds__(256, 1) void k_wino_gemm4(
+    const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
+  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+  __shared__ int ptab[WT * 9];     // element offset of output point X in y / res, or -1 (off the board / dead row)
+  const long Mt = (long)(*d_count) * (T * T);
+  // workgroup -> (tile block, cout block): block b runs on XCD b % 8.  The four cout blocks of a tile block are four
+  // CONSECUTIVE workgroups of one XCD, so its V slab (1.7 MB) comes out of HBM once and is served to the other three from
+  // that XCD's L2.  Rounds 1-2 split a tile block over an XCD pair (two cout blocks each, so that the 3.3 MB of U an XCD
+  // needs stay in its 4 MB L2): V then crossed HBM twice -- 4.0 of the layer's 7.2 GB.  With all of U (6.5 MB) wanted by
+  // every XCD the U misses go to the Infinity Cache instead; measured -0.65 % per forward (A/B, same box) and V read once.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, jb = bid >> 3;
+  const int cb = jb & 3;
+  const int tb = xcd + 8 * (jb >> 2);
+  if ((long)tb * wino_rows_per_block(T) >= Mt) return;
+  wino_wg<X, SPLIT, NS, false>(lds, ptab, vimg, uimg, scale, shift, res, y, vnext, Mt, N, T, relu, tb, cb, MODE, (int)threadIdx.x);
+}
+
+// ------------------------------------------------------------------ the whole tower in one launch
+//
+// k_wino_tower: one persistent workgroup per CU runs wino_wg for every (layer, tile block, cout block) of the tower.
+// Why: a layer is 4684 workgroups at 8192 positions of 9x9 -- 18.3 rounds of 256, and every per-layer launch pays for 19
+// (3.7 %).  With whole-board tile blocks a tile block of layer l + 1 needs nothing but the SAME tile block of layer l
+// (its four cout blocks), so the layers' (tile block) items form independent chains and one list of all of them,
+// layer-major, dealt out round-robin, is uneven by at most one item per forward instead of one round per layer.
+//
+// Who runs what.  A workgroup reads the XCD it runs on from the hardware (XCC_ID) and takes a slot 0..31 on that XCD's
+// roster: quad = slot / 4, cout block = slot % 4.  XCD x owns the tile blocks tb = x (mod 8) -- in every layer, so the
+// V slab and the y tile a workgroup reads were written by workgroups of its own XCD and are in that XCD's L2 (or behind
+// it): no cross-XCD coherence is involved, and the LDS-DMA loads carry sc1 so that they are served by L2 and never by
+// a line the CU's own vector L1 kept from two layers ago.  Quad q of XCD x runs items q, q + 8, q + 16 ... of the list
+// item = l * nbx + i  ->  (layer l, tile block x + 8 i); its four workgroups run the same item at the same time, which
+// is what lets three of them take V from L2 (as four consecutive blocks of a per-layer launch do).
+//
+// Ordering.  Producer: every wave waits for its own stores (s_waitcnt vmcnt(0): acknowledged by L2), barrier, lane 0
+// adds 1 to done[l][tb] (agent-scope atomic).  Consumer: lane 0 polls done[l-1][tb] (agent-scope load) until it is 4,
+// barrier, go.  A dependency is an item ~18 places back in every quad's own sequence, so the poll normally passes at
+// once; it gives up after kTowerSpinLimit polls and raises sched[kTowerErr] rather than hang the GPU.
+typedef WinoTowerLayer TowerLayer;
+static_assert(kWinoTowerErrWord == 8, "");
+constexpr int kTowerErr = kWinoTowerErrWord, kTowerDone = 64;      // int offsets in sched: [0..7] roster, [8] error, [64..] done[l][tb]
+constexpr int kTowerSpinLimit = 1 << 22;           // x (s_sleep + an L2 round trip, ~1 us): seconds
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 1) void k_wino_tower(const TowerLayer* __restrict__ layers, int nl, int* __restrict__ sched,
+                                                       int blocks_cap, const int* __restrict__ d_count, int N, int T) {
+  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+  __shared__ int ptab[WT * 9];
+  __shared__ int s_bc;
+  const int tid = threadIdx.x;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int xcd = (int)(xcc & 7u);
+  if (tid == 0) s_bc = atomicAdd(&sched[xcd], 1);
+  __syncthreads();
+  const int slot = s_bc;
+  if (slot >= 32) {                                  // more than 32 workgroups on one XCD: another XCD is short of them
+    if (tid == 0) atomicOr(&sched[kTowerErr], 1);
+    return;
+  }
+  const int quad = slot >> 2, cb = slot & 3;
+  const int RPB = wino_rows_per_block(T);
+  const long Mt = (long)(*d_count) * (T * T);
+  const int blocks = (int)((Mt + RPB - 1) / RPB);    // tile blocks with a live row
+  const int nbx = blocks > xcd ? (blocks - xcd + 7) >> 3 : 0;
+  const int total = nl * nbx;
+  int* done = sched + kTowerDone;
+#ifdef AGZ_TIMING_EXPERIMENTS
+  long long tw_wait = 0, tw_body = 0, tw_fin = 0, tw_items = 0;
+  const long long tw_t0 = wall_clock64();
+#define TW_NOW() ((long long)wall_clock64())
+#endif
+  for (int item = quad; item < total; item += 8) {
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const long long tw_a = TW_NOW();
+#endif
+    const int l = item / nbx, tb = xcd + 8 * (item - l * nbx);
+    if (l > 0 && tid == 0) {
+      const int* flag = done + (size_t)(l - 1) * blocks_cap + tb;
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kTowerSpinLimit) {
+          atomicOr(&sched[kTowerErr], 2);
+          break;
+        }
+      }
+    }
+    __syncthreads();      // the dependency is in; and every wave has left the previous item's epilogue (image, ptab)
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const long long tw_b = TW_NOW();
+#endif
+    const TowerLayer L = layers[l];
+    // the thread id through an opaque asm: everything the body derives from it (lane offsets, LDS addresses, tables) is
+    // recomputed per item -- a handful of VALU instructions -- instead of being hoisted out of this loop and spilled
+    // (41 VGPRs in scratch when left to the compiler: the body owns all 512 registers)
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    wino_wg<0, SPLIT, WNS, true>(lds, ptab, L.v, L.u, L.scale, L.shift, L.res, L.y, L.vnext, Mt, N, T, L.relu, tb, cb, L.mode, t);
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const long long tw_c = TW_NOW();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have reached L2
+    __syncthreads();
+    if (tid == 0) {
+      // ... and the quad leaves an item together: its four workgroups share the V slab through L2 only while they
+      // read the same K-loop stage within a few microseconds of each other (the XCD's L2 turns over every ~2.4 stages)
+      int* flag = done + (size_t)l * blocks_cap + tb;
+      if (__hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 && ++spins < kTowerSpinLimit) __builtin_amdgcn_s_sleep(2);
+      }
+    }
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const long long tw_d = TW_NOW();
+    if (tid == 0 && slot < 4 && tw_items < 384) {      // the first quad of every XCD: every item's {start, end, layer, tile block}
+      unsigned long long* r = g4_trace[256 + (xcd * 4 + slot) * 384 + tw_items];
+      r[0] = tw_b; r[1] = tw_c; r[2] = l; r[3] = tb;
+    }
+    tw_wait += tw_b - tw_a; tw_body += tw_c - tw_b; tw_fin += tw_d - tw_c; ++tw_items;
+#endif
+  }
+#ifdef AGZ_TIMING_EXPERIMENTS
+  if (tid == 0) {      // per persistent workgroup: {xcd | slot << 8, items, wait, body, finish, start, end} (10 ns ticks)
+    unsigned long long* r = g4_trace[blockIdx.x];
+    r[0] = (unsigned long long)xcd | ((unsigned long long)slot << 8);
+    r[1] = tw_items; r[2] = tw_wait; r[3] = tw_body; r[4] = tw_fin; r[5] = tw_t0; r[6] = TW_NOW();
+  }
+#endif
+}
+
+// one workgroup per CU: which XCD does block b run on?  (the tower kernel does not depend on the answer being b % 8,
+// only on every XCD getting 32 of 256 resident workgroups: checked once per process, on the device it will run on)
+__global__ void k_xcd_census(int* out) {
+  __shared__ float hog[150 * 1024 / 4];      // one workgroup per CU, like the tower kernel
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) {
+    hog[0] = 1.f;
+    atomicAdd(&out[xcc & 7u], 1);
+    const long long t0 = wall_clock64();      // stay resident until the whole grid is (100 us)
+    while ((long long)wall_clock64() - t0 < 10000) __builtin_amdgcn_s_sleep(32);
+    if (hog[0] == 2.f) out[8] = 1;
+  }
+}
+
 // ------------------------------------------------------------------ host side
 
 // Flux [kw,kh,cin,cout] column-major -> stage images U[cout block][stage][plane][cout 64][8] with
@@ -894,6 +1053,59 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
     hipLaunchKernelGGL((k_wino_gemm4<2>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
   else
     hipLaunchKernelGGL((k_wino_gemm4<1>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+}
+
+size_t wino_tower_sched_ints(int layers, int bcap, int N) {
+  const int T = (N + 2) / 3;
+  return (size_t)kTowerDone + (size_t)layers * wino_blocks(bcap, T);
+}
+
+// 256 resident workgroups, 32 on every XCD?  (cached per device)
+bool wino_tower_supported(hipStream_t s) {
+  static int cached[64];      // 0 unknown, 1 yes, 2 no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (cached[dev]) return cached[dev] == 1;
+  hipDeviceProp_t prop;
+  bool ok = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount == 256;
+  if (ok) {
+    int* d = nullptr;
+    int h[9] = {0};
+    ok = hipMalloc((void**)&d, sizeof(h)) == hipSuccess;
+    if (ok) {
+      (void)hipMemsetAsync(d, 0, sizeof(h), s);
+      hipLaunchKernelGGL(k_xcd_census, dim3(256), dim3(64), 0, s, d);
+      ok = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+      (void)hipFree(d);
+      for (int x = 0; ok && x < 8; ++x) ok = h[x] == 32;
+    }
+  }
+  cached[dev] = ok ? 1 : 2;
+  return ok;
+}
+
+// the tower's layers (device array of TowerLayer, see agz_nn.hip) in one launch; sched: wino_tower_sched_ints() ints
+void launch_wino_tower(const void* d_layers, int layers, int* d_sched, const int* d_count, int bcap, int N, bool split, hipStream_t s) {
+  const int T = (N + 2) / 3;
+  AGZ_REQUIRE(wino_whole_boards(T), AGZ_BAD_ARGUMENT, "the persistent tower kernel needs whole-board tile blocks");
+  const int blocks_cap = (int)wino_blocks(bcap, T);
+  (void)hipMemsetAsync(d_sched, 0, sizeof(int) * wino_tower_sched_ints(layers, bcap, N), s);
+  if (split)
+    hipLaunchKernelGGL((k_wino_tower<true>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T);
+  else
+    hipLaunchKernelGGL((k_wino_tower<false>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T);
+#ifdef AGZ_TIMING_EXPERIMENTS
+  static int traced = 0;
+  if (getenv("AGZ_TOWER_TRACE") && ++traced == 3) {
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[256 + 32 * 384][8];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_trace), sizeof(host));
+    if (FILE* f = fopen(getenv("AGZ_TOWER_TRACE"), "wb")) {
+      fwrite(host, 1, sizeof(host), f);
+      fclose(f);
+    }
+  }
+#endif
 }
 
 }  // namespace agz

@@ -458,6 +458,9 @@ function copy_weights!(dst::Engine, src::Engine)
 end
 
 # tower arithmetic of an engine's network: :f32 (default, exact) or :f16 (fp16 operands, f32 accumulate)
+# the f32 Winograd tower as one persistent launch (same bits as one launch per layer, include/agz.h)
+set_tower_persistent!(e::Engine, on::Bool) =
+  check(e, ccall((:agz_net_set_tower_persistent, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, on ? 1 : 0))
 set_precision!(e::Engine, p::Symbol) =
   check(e, ccall((:agz_net_set_precision, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, p === :f16 ? 1 : 0))
 

@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32s"],
                     help="tower arithmetic: f32 (default, the BASELINE metric), f16 = the fp16 MFMA path of BASELINE configs[4], "
                          "f32s = the f32 network with Winograd operands split into two f16 halves (fp16 MFMA, f32-grade results)")
+    ap.add_argument("--tower-persistent", action="store_true",
+                    help="run the f32 Winograd tower as one persistent launch (agz_net_set_tower_persistent; same bits, DESIGN.md 4f)")
     ap.add_argument("--no-alt-precision", action="store_true",
                     help="skip the extra (untimed for `value`) leg that repeats the K steps with --precision f32s")
     ap.add_argument("--generation", type=int, default=0, metavar="G",
@@ -181,6 +183,8 @@ def main():
                     stagger_moves=args.stagger)
     eng.init_synthetic(0)
     eng.set_precision(args.precision)
+    if args.tower_persistent:
+        eng.set_tower_persistent(True)
     eng.start(0)
 
     def barrier():

@@ -132,6 +132,12 @@ agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_
 /* tower-convolution algorithm: 1 (default) = Winograd F(3x3,3x3) on the f32 MFMA, 0 = direct
  * implicit GEMM on the f32 MFMA.  Both are f32 end to end; they differ by rounding only. */
 agz_status agz_net_set_winograd(agz_engine* e, int32_t on);
+/* the f32 Winograd tower as one launch per layer (0, default) or as ONE persistent launch over all its layers (1: used
+ * wherever it applies -- board sizes whose tile blocks hold whole boards (N <= 12), a 256-CU device).  The same device
+ * function does the work either way: outputs are bit-identical (tests/test_gpu_tower.py).  The persistent form needs
+ * 3.7 % fewer cycles (no partly filled last workgroup round per layer) and, on a power-limited MI355X, runs at a
+ * clock 4 % lower: the same wall time. */
+agz_status agz_net_set_tower_persistent(agz_engine* e, int32_t on);
 /* tower arithmetic of the network selected by agz_net_select.  AGZ_PRECISION_F32 (default): exact
  * f32 end to end -- the parity target of BASELINE.json's metric.  AGZ_PRECISION_F16: the "fp16 MFMA
  * path" of BASELINE.json configs[4]: tower activations and weights are rounded to IEEE half, products

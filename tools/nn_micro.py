@@ -18,6 +18,7 @@ ap.add_argument("--batches", type=int, nargs="+", default=[1024, 4096, 8192])
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--algos", type=int, nargs="+", default=[1, 0], help="1 = winograd, 0 = direct")
 ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32s"], help="f16 = fp16-operand tower (algos ignored)")
+ap.add_argument("--tower-persistent", type=int, default=0, help="1 = the whole tower as one persistent launch (k_wino_tower)")
 args = ap.parse_args()
 
 N, t = args.board, args.tower
@@ -25,6 +26,7 @@ P = N * N
 eng = ag.Engine(board_size=N, tower_height=t, games=1, num_readouts=1, max_nodes_per_game=8)
 eng.init_synthetic(0)
 eng.set_precision(args.precision)
+eng.set_tower_persistent(bool(args.tower_persistent))
 if args.precision == "f16":
     args.algos = [1]
     PEAK = 2500.0
