@@ -805,7 +805,7 @@ constexpr int kTowerSpinLimit = 1 << 22;           // x (s_sleep + an L2 round t
 
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 1) void k_wino_tower(const TowerLayer* __restrict__ layers, int nl, int* __restrict__ sched,
-                                                       int blocks_cap, const int* __restrict__ d_count, int N, int T) {
+                                                       int blocks_cap, const int* __restrict__ d_count, int N, int T, int order) {
   __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
   __shared__ int ptab[WT * 9];
   __shared__ int s_bc;
@@ -832,11 +832,24 @@ __global__ __launch_bounds__(256, 1) void k_wino_tower(const TowerLayer* __restr
   const long long tw_t0 = wall_clock64();
 #define TW_NOW() ((long long)wall_clock64())
 #endif
-  for (int item = quad; item < total; item += 8) {
+  // order 0: the XCD's list layer-major (every quad on the same layer, a tile block's next layer ~18 items later);
+  // order 1: chain-major -- a quad takes a tile block through ALL layers before its next one, so the V it reads was
+  // written one item earlier (by itself) and is still in the Infinity Cache
+  const int nitems = order == 0 ? (total > quad ? (total - quad + 7) >> 3 : 0) : (nbx > quad ? ((nbx - quad + 7) >> 3) * nl : 0);
+  for (int k = 0; k < nitems; ++k) {
 #ifdef AGZ_TIMING_EXPERIMENTS
     const long long tw_a = TW_NOW();
 #endif
-    const int l = item / nbx, tb = xcd + 8 * (item - l * nbx);
+    int l, tb;
+    if (order == 0) {
+      const int item = quad + 8 * k;
+      l = item / nbx;
+      tb = xcd + 8 * (item - l * nbx);
+    } else {
+      const int j = k / nl;
+      l = k - j * nl;
+      tb = xcd + 8 * (quad + 8 * j);
+    }
     if (l > 0 && tid == 0) {
       const int* flag = done + (size_t)(l - 1) * blocks_cap + tb;
       int spins = 0;
@@ -1090,10 +1103,11 @@ void launch_wino_tower(const void* d_layers, int layers, int* d_sched, const int
   AGZ_REQUIRE(wino_whole_boards(T), AGZ_BAD_ARGUMENT, "the persistent tower kernel needs whole-board tile blocks");
   const int blocks_cap = (int)wino_blocks(bcap, T);
   (void)hipMemsetAsync(d_sched, 0, sizeof(int) * wino_tower_sched_ints(layers, bcap, N), s);
+  static const int order = getenv("AGZ_TOWER_ORDER") ? atoi(getenv("AGZ_TOWER_ORDER")) : 0;
   if (split)
-    hipLaunchKernelGGL((k_wino_tower<true>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T);
+    hipLaunchKernelGGL((k_wino_tower<true>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T, order);
   else
-    hipLaunchKernelGGL((k_wino_tower<false>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T);
+    hipLaunchKernelGGL((k_wino_tower<false>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T, order);
 #ifdef AGZ_TIMING_EXPERIMENTS
   static int traced = 0;
   if (getenv("AGZ_TOWER_TRACE") && ++traced == 3) {
