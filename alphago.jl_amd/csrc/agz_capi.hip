@@ -561,5 +561,8 @@ int32_t agz_debug_counters(agz_engine* e, uint64_t* out, int32_t cap) {
 agz_status agz_debug_set_stagger(agz_engine* e, int32_t moves) {
   return guard(e, [&](agz::Engine& E) { E.debug_set_stagger(moves); });
 }
+agz_status agz_debug_mfma_sustained(agz_engine* e, int32_t millis, float* tflops_out) {
+  return guard(e, [&](agz::Engine& E) { *tflops_out = E.net().mfma_sustained_tflops(millis); });
+}
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 #include "agz_nn.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 
 #include "../../include/agz_draws.h"
@@ -788,6 +789,53 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
                      d_pfcb_.p, d_pi, d_v, d_count, P_, A_);
   if (prof_on_ && prof_fwd_ < kProfMax) prof_fwd_++;
   AGZ_HIP(hipGetLastError());
+}
+
+// registers only: no memory, no LDS -- the matrix pipes of every SIMD busy, and the clock wherever the power limit puts it
+__global__ __launch_bounds__(256) void k_mfma_f32_sustained(int iters, float* out) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const float a = 1.f + threadIdx.x * 1e-6f, b = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
+  if (s == 123.456f) out[0] = s;
+}
+
+float Net::mfma_sustained_tflops(int millis) {
+  AGZ_REQUIRE(millis >= 50 && millis <= 5000, AGZ_BAD_ARGUMENT, "mfma_sustained_tflops: %d ms (50..5000)", millis);
+  DevBuf<float> out;
+  out.alloc(16);
+  hipEvent_t e0, e1;
+  AGZ_HIP(hipEventCreate(&e0));
+  AGZ_HIP(hipEventCreate(&e1));
+  const int iters = 10000, grid = 1024;      // 4 workgroups of 4 waves per CU; ~11 ms per launch
+  const double flop = (double)grid * 4 * iters * 8.0 * 4096.0;
+  std::vector<double> tf;
+  double spent = 0.0;
+  while (spent < millis) {
+    AGZ_HIP(hipEventRecord(e0, stream_));
+    hipLaunchKernelGGL(k_mfma_f32_sustained, dim3(grid), dim3(256), 0, stream_, iters, out.p);
+    AGZ_HIP(hipEventRecord(e1, stream_));
+    AGZ_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    AGZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    tf.push_back(flop / (ms * 1e-3) / 1e12);
+    spent += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  std::vector<double> tail(tf.begin() + tf.size() / 2, tf.end());
+  std::sort(tail.begin(), tail.end());
+  return (float)tail[tail.size() / 2];
 }
 
 Net::~Net() {

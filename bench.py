@@ -141,6 +141,7 @@ def main():
                          "f32s = the f32 network with Winograd operands split into two f16 halves (fp16 MFMA, f32-grade results)")
     ap.add_argument("--tower-persistent", action="store_true",
                     help="run the f32 Winograd tower as one persistent launch (agz_net_set_tower_persistent; same bits, DESIGN.md 4f)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the 0.4 s sustained-MFMA-rate measurement behind the timed region")
     ap.add_argument("--no-alt-precision", action="store_true",
                     help="skip the extra (untimed for `value`) leg that repeats the K steps with --precision f32s")
     ap.add_argument("--generation", type=int, default=0, metavar="G",
@@ -403,6 +404,18 @@ def main():
             "executed_flop_per_launch_avg": conv_flop * wino_ratio / max(conv_n, 1),
             "algorithmic_flop_per_launch_avg": conv_flop / max(conv_n, 1),
         }
+        if not f16 and not f32s and exe_tf is not None and not args.no_sustained:
+            # context, not the contract's `peak`: what THIS board sustains on f32 MFMAs alone (power-limited clock), measured
+            # now, after the timed region (0.4 s of back-to-back register-only MFMA launches)
+            try:
+                sus = eng.mfma_sustained_tflops(400)
+                roofline["sustained_mfma"] = {
+                    "value": sus, "unit": "TFLOP/s", "frac_of_nominal_peak": sus / peak, "achieved_over_sustained": exe_tf / sus,
+                    "what": "v_mfma_f32_32x32x2_f32 from registers only, one launch of ~10 ms after another for 0.4 s on this "
+                            "GPU, median of the second half: the board's power limit holds the clock near 1.9 GHz",
+                }
+            except Exception as ex:      # never at the expense of the line
+                roofline["sustained_mfma"] = {"error": f"{type(ex).__name__}: {ex}"}
         out = {
             "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)" + (" [fp16 tower]" if f16 else "")
                       + (" [f32 as split f16 operands]" if f32s else ""),

@@ -31,6 +31,11 @@ int32_t agz_debug_counters(agz_engine* e, uint64_t* out, int32_t cap);
  * agz_selfplay_start; not available in arena_mode. */
 agz_status agz_debug_set_stagger(agz_engine* e, int32_t moves);
 
+/* Measurement context for bench.py's roofline object: the f32 MFMA rate (TFLOP/s) this board SUSTAINS on nothing but
+ * independent v_mfma_f32_32x32x2_f32 from registers -- back-to-back ~10 ms launches for `millis` (50..5000), median of the
+ * second half.  On an MI355X at its power limit: ~124, i.e. 0.79 of the nominal 157.3.  Synchronises. */
+agz_status agz_debug_mfma_sustained(agz_engine* e, int32_t millis, float* tflops_out);
+
 #ifdef __cplusplus
 }
 #endif
