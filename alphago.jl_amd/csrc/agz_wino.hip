@@ -318,7 +318,7 @@ __device__ unsigned long long g4_trace[16384][8];
 // MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
 // X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
 //   1 = K loop only; 2 = no epilogue 2; 3 = epilogue 2 without its global stores; 4 = no DMA after the prologue;
-//   5 = no MFMA; 6 = no LDS operand reads; 13 / 14 / 15 = every stage's DMA (of both operands / U / V) from the same two (L2-resident) stage images
+//   5 = no MFMA; 6 = no LDS operand reads; 7..10, 16..18 = projections (see the K loop); 13 / 14 / 15 = every stage's DMA (of both operands / U / V) from the same two (L2-resident) stage images
 // NS: stages of the K loop (input channels / 4): 64, or 8 for the stem
 // COH: every LDS-DMA load carries sc1 (served by L2, not by this CU's L1): the persistent tower kernel below reads what
 // other workgroups of its XCD wrote earlier in the same launch.  Costs nothing (same-box A/B +-0).
@@ -344,7 +344,9 @@ __device__ __forceinline__ void wino_wg(
   }
   G4_STAMP(1);
 #endif
-  const float* asrc = vimg + (long)tb * NS * A_STAGE;
+  // (timing 16 / 17 / 18: what a quad-private, cache-resident V scratch would buy -- 64 slabs instead of one per tile
+  // block: 17 the V loads come from slab tb % 64, 16 the V stores go there, 18 both)
+  const float* asrc = vimg + (long)((X == 17 || X == 18) ? (tb & 63) : tb) * NS * A_STAGE;
   const float* bsrc = uimg + (long)cb * NS * B_STAGE;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0];
 
@@ -693,7 +695,7 @@ __device__ __forceinline__ void wino_wg(
           d[q] = (f32x4){a[0], a[1], b[0], b[1]};
         }
       }
-      float* g = vnext + ((long)tb * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
+      float* g = vnext + ((long)((X == 16 || X == 18) ? (tb & 63) : tb) * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
       // B^T d B on channel PAIRS (v_pk_*_f32: two channels per VALU instruction; no MFMA runs beside this): the
       // arithmetic of bt5 above, operation for operation (9 packed operations per five values)
       auto bt5p = [](f32x2 x0, f32x2 x1, f32x2 x2, f32x2 x3, f32x2 x4, f32x2* r) {      // bt5, two channels at a time
@@ -1045,7 +1047,7 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   if (xp && y && vnext && res && !split) {
     auto kern = xp == 1 ? k_wino_gemm4<3, 1> : xp == 2 ? k_wino_gemm4<3, 2> : xp == 3 ? k_wino_gemm4<3, 3>
               : xp == 4 ? k_wino_gemm4<3, 4> : xp == 5 ? k_wino_gemm4<3, 5> : xp == 6 ? k_wino_gemm4<3, 6>
-              : xp == 13 ? k_wino_gemm4<3, 13> : xp == 14 ? k_wino_gemm4<3, 14> : xp == 15 ? k_wino_gemm4<3, 15> : xp == 7 ? k_wino_gemm4<3, 7> : xp == 8 ? k_wino_gemm4<3, 8> : xp == 9 ? k_wino_gemm4<3, 9> : xp == 10 ? k_wino_gemm4<3, 10>
+              : xp == 16 ? k_wino_gemm4<3, 16> : xp == 17 ? k_wino_gemm4<3, 17> : xp == 18 ? k_wino_gemm4<3, 18> : xp == 13 ? k_wino_gemm4<3, 13> : xp == 14 ? k_wino_gemm4<3, 14> : xp == 15 ? k_wino_gemm4<3, 15> : xp == 7 ? k_wino_gemm4<3, 7> : xp == 8 ? k_wino_gemm4<3, 8> : xp == 9 ? k_wino_gemm4<3, 9> : xp == 10 ? k_wino_gemm4<3, 10>
               : xp == 11 ? k_wino_gemm4<1, 0> : xp == 12 ? k_wino_gemm4<2, 0> : k_wino_gemm4<3, 0>;
     hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, xp == 12 ? nullptr : res, y, vnext, d_count, N, T, relu);
     return;
