@@ -71,3 +71,13 @@ def test_persistent_tower_matches_the_oracle():
     assert np.abs(gpi - pi).max() <= TOL and np.abs(gv - v).max() <= TOL, (np.abs(gpi - pi).max(), np.abs(gv - v).max())
     L.or_net_free(onet)
     eng.close()
+
+
+def test_sustained_mfma_rate_is_a_sane_number():
+    """bench.py's roofline.sustained_mfma: between a third of and the whole nominal f32 MFMA peak; argument checked."""
+    eng = ag.Engine(board_size=5, games=1, tower_height=1, num_readouts=8, max_nodes_per_game=16)
+    tf = eng.mfma_sustained_tflops(100)
+    assert 50.0 < tf <= 160.0, tf
+    with pytest.raises(ag.AgzError):
+        eng.mfma_sustained_tflops(10)
+    eng.close()
