@@ -715,8 +715,13 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       const bool persistent = tower_persistent_ && !dense && stem_wino && wino_tower_supported(stream_);
       if (persistent) {
         // the same layers as the loop below, as a table for ONE persistent launch (k_wino_tower)
-        AGZ_REQUIRE(!tower_err_ || *tower_err_ == 0, AGZ_HIP_ERROR,
-                    "the persistent tower kernel of the previous forward gave up waiting for a tile block (scheduler error word set)");
+        if (tower_err_ && *tower_err_) {
+          const int err = *tower_err_;
+          *tower_err_ = 0;
+          AGZ_REQUIRE(false, AGZ_HIP_ERROR,
+                      "the persistent tower kernel of an earlier forward gave up (scheduler error word %d: 1 = more than 32 "
+                      "workgroups on one XCD, 2 = a tile block's producer never arrived); its outputs were garbage", err);
+        }
         const int nl = 2 * tower_;
         std::vector<WinoTowerLayer> tab(nl);
         float *pa = a, *pb = b, *vc = vcur, *vn = vnxt;

@@ -852,18 +852,23 @@ __global__ __launch_bounds__(256, 1) void k_wino_tower(const TowerLayer* __restr
       l = k - j * nl;
       tb = xcd + 8 * (quad + 8 * j);
     }
+    if (tid == 0) s_bc = 0;
     if (l > 0 && tid == 0) {
       const int* flag = done + (size_t)(l - 1) * blocks_cap + tb;
       int spins = 0;
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > kTowerSpinLimit) {
+        // give up after kTowerSpinLimit polls -- or as soon as anybody else has: one stuck chain must not cost every
+        // waiter its own time-out
+        if (++spins > kTowerSpinLimit || ((spins & 1023) == 0 && __hip_atomic_load(&sched[kTowerErr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           atomicOr(&sched[kTowerErr], 2);
+          s_bc = 1;
           break;
         }
       }
     }
     __syncthreads();      // the dependency is in; and every wave has left the previous item's epilogue (image, ptab)
+    if (s_bc) return;     // (uniform: the forward's output is garbage and Net::forward reports the error word)
 #ifdef AGZ_TIMING_EXPERIMENTS
     const long long tw_b = TW_NOW();
 #endif
