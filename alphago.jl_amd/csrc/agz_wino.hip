@@ -374,18 +374,26 @@ __device__ __forceinline__ void wino_wg(
     const long tile = (long)tb * RPB + row;
     int off = -1;
     if (row < RPB && tile < Mt) {
-      const int b = (int)(tile / TT), t = (int)(tile % TT);
-      const int pi = 3 * (t / T) + k / 3, pj = 3 * (t % T) + k % 3;
-      if (pi < N && pj < N) off = (b * P + pi + N * pj) * kC + cb * WC;      // < 2^31: 8192 x 361 x 256 = 7.6e8
+      // 32-bit divisions (tile < Mt < 2^31, checked by the launchers): the 64-bit ones were a third of this set-up, which
+      // is NOT hidden behind the first stages' flight -- they land before it is done (wall-clock trace: 3.5 us of set-up,
+      // 0.1 us of waiting)
+      const unsigned tile32 = (unsigned)tile, b = tile32 / (unsigned)TT, t = tile32 - b * (unsigned)TT;
+      const unsigned ti = t / (unsigned)T, k3 = (unsigned)k / 3u;
+      const int pi = (int)(3 * ti + k3), pj = (int)(3 * (t - ti * T) + ((unsigned)k - 3 * k3));
+      if (pi < N && pj < N) off = ((int)b * P + pi + N * pj) * kC + cb * WC;      // < 2^31: 8192 x 361 x 256 = 7.6e8
     }
     ptab[idx] = off;
   }
 
+  // (not zeroed: the first MFMA of every plane takes C = 0 as an inline constant -- 400 register writes per lane that
+  // sat, exposed, between the workgroup's start and its first MFMA)
   f32x16 acc[WXI];
+  if (X == 5) {      // (the no-MFMA timing variant never writes them)
 #pragma unroll
-  for (int i = 0; i < WXI; ++i)
+    for (int i = 0; i < WXI; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  }
 
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
   const int brot = wino_rot(brow);
@@ -421,6 +429,23 @@ __device__ __forceinline__ void wino_wg(
   // Wait states (cdna_hip_programming.md 5.7): an accumulate chain needs none; the leading s_nop 1 covers a
   // compiler v_mov into an A/B operand; the D -> VALU distance is padded once, after the K loop.
   auto in_agpr = [](int k) { return k % 5 < 3; };
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto mma0 = [&](int k, const a_t& a, const float2& b) {      // the plane's first k-step: D = A B + 0
+    if constexpr (SPLIT) {
+      const h8 ah = __builtin_bit_cast(h8, a);
+      const f32x4 bb = {b.x, b.y, b.x, b.y};
+      const h8 bh = __builtin_bit_cast(h8, bb);
+      if (in_agpr(k)) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, zero16, 0, 0, 0);
+      else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[k]) : "v"(ah), "v"(bh));
+    } else if (in_agpr(k)) {
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, zero16, 0, 0, 0);
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[k], 0, 0, 0);
+    } else {
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0\n\tv_mfma_f32_32x32x2_f32 %0, %3, %4, %0"
+                   : "=&v"(acc[k])
+                   : "v"(a.x), "v"(b.x), "v"(a.y), "v"(b.y));
+    }
+  };
   auto mma = [&](int k, const a_t& a, const float2& b) {
     if constexpr (SPLIT) {
       const h8 ah = __builtin_bit_cast(h8, a);
@@ -448,8 +473,14 @@ __device__ __forceinline__ void wino_wg(
   };
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   f32x2_t dum0 = {1.f, 2.f}, dum1 = {3.f, 4.f}, dumc = {0.5f, 0.25f};
+#ifdef AGZ_X_PROLOGUE_STAMP
+  G4_STAMP(6);      // (this build only: slot 6 = set-up done, slot 7 = first stage landed and published)
+#endif
   wait_stage();
   __syncthreads();
+#ifdef AGZ_X_PROLOGUE_STAMP
+  G4_STAMP(7);
+#endif
 #pragma unroll
   for (int k = 0; k < LA; ++k) load(lds, k, ra[k], rb[k]);
 
@@ -477,8 +508,8 @@ __device__ __forceinline__ void wino_wg(
     else glds16(g, lds0 + (unsigned)(i * 256) * 4u);
   };
   int buf = 0;
-  auto stage = [&](int st, auto more_c, auto next_c) {
-    constexpr bool more = decltype(more_c)::value, next = decltype(next_c)::value;
+  auto stage = [&](int st, auto more_c, auto next_c, auto first_c) {
+    constexpr bool more = decltype(more_c)::value, next = decltype(next_c)::value, first = decltype(first_c)::value;
     const int nbuf = buf == 2 ? 0 : buf + 1;          // stage st+1
     const int dbuf = buf == 0 ? 2 : buf - 1;          // stage st+2 (= the buffer stage st-1 was read from)
     const float* L = lds + buf * STAGE;
@@ -513,13 +544,18 @@ __device__ __forceinline__ void wino_wg(
         if (res) rdma((next ? 13 : 26) + k - D0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (X != 5) mma(k, ra[k % RING], rb[k % RING]);
+      if (X != 5) {
+        if (first) mma0(k, ra[k % RING], rb[k % RING]);
+        else mma(k, ra[k % RING], rb[k % RING]);
+      }
     }
     buf = nbuf;
   };
-  for (int st = 0; st < NS - 2; ++st) stage(st, std::true_type{}, std::true_type{});
-  stage(NS - 2, std::false_type{}, std::true_type{});
-  stage(NS - 1, std::false_type{}, std::false_type{});
+  static_assert(NS >= 4, "stage 0 is peeled off the loop");
+  stage(0, std::true_type{}, std::true_type{}, std::true_type{});
+  for (int st = 1; st < NS - 2; ++st) stage(st, std::true_type{}, std::true_type{}, std::false_type{});
+  stage(NS - 2, std::false_type{}, std::true_type{}, std::false_type{});
+  stage(NS - 1, std::false_type{}, std::false_type{}, std::false_type{});
 
   // the asm MFMAs' D registers -> VALU readers below: 18 wait states.  The pad must NAME those registers, or the
   // scheduler is free to lift a register-only VALU read of them above it (seen: 4e-4 errors on some lanes)
@@ -585,12 +621,16 @@ __device__ __forceinline__ void wino_wg(
 #pragma unroll
     for (int k = 0; k < 9; ++k)
       if (RESPF) asm volatile("" : "+v"(o[k]));
+#ifndef AGZ_X_PROLOGUE_STAMP
     G4_STAMP(6);
+#endif
     if (res) {                                    // the residual tile has landed, for every wave
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+#ifndef AGZ_X_PROLOGUE_STAMP
     G4_STAMP(7);
+#endif
     // img = (residual +) value.  ds_add_f32 would do the sum in one instruction, but LDS float atomics run at a
     // fraction of the ds_write rate (+0.75 ms per layer measured): read the nine residuals of a row, add, write
     auto rows = [&](auto with_res) {
@@ -1018,6 +1058,7 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   const int blocks = (int)wino_blocks(bcap, T);
   const int per_xcd = 4 * ((blocks + 7) / 8);   // see the placement comment in k_wino_gemm4
   const dim3 grid(8 * per_xcd), block(256);
+  AGZ_REQUIRE((long)(blocks + 1) * WT < (1L << 31), AGZ_BAD_ARGUMENT, "batch of %d positions: tile index exceeds 32 bits", bcap);
   if (ns == kWinoStemStages) {                   // the stem: its output is always wanted in HBM (block 0's residual)
     constexpr int S = kWinoStemStages;
     if (split) {
