@@ -504,9 +504,10 @@ __device__ __forceinline__ void wino_wg(
     const int i = wave + 4 * n;
     const int Xp = 4 * i + (lane >> 4), u = lane & 15;
     const int off = ptab[Xp];
-    const float* g = res + (off >= 0 ? off + 4 * (u ^ (Xp & 15)) : 0);      // dead points: any valid address
-    if constexpr (COH) glds16_l2(g, lds0 + (unsigned)(i * 256) * 4u);
-    else glds16(g, lds0 + (unsigned)(i * 256) * 4u);
+    // uniform base + 32-bit byte offset (< 2^32: checked by the launchers); dead points: any valid address
+    const unsigned boff = off >= 0 ? 4u * (unsigned)(off + 4 * (u ^ (Xp & 15))) : 0u;
+    if constexpr (COH) glds16s_l2(res, boff, lds0 + (unsigned)(i * 256) * 4u);
+    else glds16s(res, boff, lds0 + (unsigned)(i * 256) * 4u);
   };
   int buf = 0;
   auto stage = [&](int st, auto more_c, auto next_c, auto first_c) {
@@ -704,7 +705,11 @@ __device__ __forceinline__ void wino_wg(
     // out, because the compiler cannot see that and spends fifty run-time divisions by 3 on `pi / 3`, `pi % 3`.  A point
     // off the board (or a lane that emits nothing) reads a block of zeros behind the image instead of being masked out:
     // no exec juggling around 25 (50) conditional loads per task.
-    int pbase[25], pxm[25];            // float offset of point X's row in img, and its swizzle X & 15
+    // adr[q]: LDS byte address of patch point q's unit for stage `wave` (this wave's first): row Xq of the image, unit
+    // wave ^ (Xq & 15), and in the f32 form the lane's half of it.  Stage wave + 4 it is the same address with bits 6-7
+    // XORed by it (the image is 256-byte aligned and a row is 256 bytes): one v_xor per read in the loop below instead
+    // of xor + shift-add + add (-200 instructions per wave and workgroup)
+    unsigned adr[25];
 #pragma unroll
     for (int u = 0; u < 5; ++u)
 #pragma unroll
@@ -714,25 +719,27 @@ __device__ __forceinline__ void wino_wg(
         const int pi = 3 * ti - 1 + u, pj = 3 * tj - 1 + v;
         const bool ok = live && emit && pi >= 0 && pi < N && pj >= 0 && pj < N;
         const int Xq = (ku * 3 + kv) * WT + row + du * T + dv;
-        pbase[u * 5 + v] = ok ? Xq * WC : IMG_FLOATS;
-        pxm[u * 5 + v] = ok ? (Xq & 15) : 0;
+        const int pb = ok ? Xq * WC : IMG_FLOATS, xm = ok ? (Xq & 15) : 0;
+        // a V image row is one plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1 (wino_v_off)
+        adr[u * 5 + v] = lds0 + 4u * (unsigned)(pb + 4 * (wave ^ xm) + (SPLIT ? 0 : 2 * ((row >> 4) & 1)));
       }
-    // a V image row is one plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1 (wino_v_off)
-    const int sw2 = 2 * ((row >> 4) & 1);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    static_assert(WC / WK == 16, "four stages per wave");
 #pragma unroll 1
-    for (int sl = wave; sl < WC / WK; sl += 4) {      // (unrolling by 2 for ILP: no change)
+    for (int it = 0; it < 4; ++it) {      // (unrolling by 2 for ILP: no change)
+      const int sl = wave + 4 * it;
+      const unsigned xo = (unsigned)it << 6;
       f32x4 d[25];
 #pragma unroll
       for (int q = 0; q < 25; ++q) {
+        const unsigned a0 = adr[q] ^ xo;
         if constexpr (SPLIT) {
-          d[q] = *reinterpret_cast<const f32x4*>(img + pbase[q] + 4 * (sl ^ pxm[q]));
+          d[q] = *(const __attribute__((address_space(3))) f32x4*)(size_t)a0;
         } else {
           // the lane's two channel pairs in the order its V row wants them (rows with bit 4 set store pair 1 first): two
           // 8-byte reads at lane-dependent halves of the unit instead of 104 selects per task on the way out
-          const float* u = img + pbase[q] + 4 * (sl ^ pxm[q]);
-          const f32x2 a = *reinterpret_cast<const f32x2*>(u + sw2);
-          const f32x2 b = *reinterpret_cast<const f32x2*>(u + (2 - sw2));
+          const f32x2 a = *(const __attribute__((address_space(3))) f32x2*)(size_t)a0;
+          const f32x2 b = *(const __attribute__((address_space(3))) f32x2*)(size_t)(a0 ^ 8u);
           d[q] = (f32x4){a[0], a[1], b[0], b[1]};
         }
       }
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
-  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+  __shared__ __attribute__((aligned(256))) float lds[3 * STAGE];
   __shared__ int ptab[WT * 9];     // element offset of output point X in y / res, or -1 (off the board / dead row)
   const long Mt = (long)(*d_count) * (T * T);
   // workgroup -> (tile block, cout block): block b runs on XCD b % 8.  The four cout blocks of a tile block are four
@@ -849,7 +856,7 @@ constexpr int kTowerSpinLimit = 1 << 22;           // x (s_sleep + an L2 round t
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 1) void k_wino_tower(const TowerLayer* __restrict__ layers, int nl, int* __restrict__ sched,
                                                        int blocks_cap, const int* __restrict__ d_count, int N, int T, int order) {
-  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+  __shared__ __attribute__((aligned(256))) float lds[3 * STAGE];
   __shared__ int ptab[WT * 9];
   __shared__ int s_bc;
   const int tid = threadIdx.x;
@@ -1059,7 +1066,8 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   const int blocks = (int)wino_blocks(bcap, T);
   const int per_xcd = 4 * ((blocks + 7) / 8);   // see the placement comment in k_wino_gemm4
   const dim3 grid(8 * per_xcd), block(256);
-  AGZ_REQUIRE((long)(blocks + 1) * WT < (1L << 31), AGZ_BAD_ARGUMENT, "batch of %d positions: tile index exceeds 32 bits", bcap);
+  AGZ_REQUIRE((long)(blocks + 1) * WT < (1L << 31) && (long)bcap * N * N * kC * 4 < (1L << 32), AGZ_BAD_ARGUMENT,
+              "batch of %d positions at %dx%d: tile index / activation byte offset exceeds 32 bits", bcap, N, N);
   if (ns == kWinoStemStages) {                   // the stem: its output is always wanted in HBM (block 0's residual)
     constexpr int S = kWinoStemStages;
     if (split) {
@@ -1150,6 +1158,8 @@ bool wino_tower_supported(hipStream_t s) {
 void launch_wino_tower(const void* d_layers, int layers, int* d_sched, const int* d_count, int bcap, int N, bool split, hipStream_t s) {
   const int T = (N + 2) / 3;
   AGZ_REQUIRE(wino_whole_boards(T), AGZ_BAD_ARGUMENT, "the persistent tower kernel needs whole-board tile blocks");
+  AGZ_REQUIRE((long)(wino_blocks(bcap, T) + 1) * WT < (1L << 31) && (long)bcap * N * N * kC * 4 < (1L << 32), AGZ_BAD_ARGUMENT,
+              "batch of %d positions at %dx%d: tile index / activation byte offset exceeds 32 bits", bcap, N, N);
   const int blocks_cap = (int)wino_blocks(bcap, T);
   (void)hipMemsetAsync(d_sched, 0, sizeof(int) * wino_tower_sched_ints(layers, bcap, N), s);
   static const int order = getenv("AGZ_TOWER_ORDER") ? atoi(getenv("AGZ_TOWER_ORDER")) : 0;
