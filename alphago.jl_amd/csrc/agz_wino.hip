@@ -638,14 +638,22 @@ __device__ __forceinline__ void wino_wg(
     auto rows = [&](auto with_res) {
 #pragma unroll
       for (int e0 = 0; e0 < 16; e0 += 4) {          // four tile rows at a time: 36 LDS reads behind one wait
-        float* p0[4];
+        // output k of a (row, cout) at byte k * 16 KB from the row's address: three bases 64 KB apart, so that every
+        // access is base + a 16-bit immediate (the compiler otherwise adds a 32-bit constant in front of each access
+        // with k >= 4) and neighbouring k pair up in ds_read2st64 / ds_write2st64
+        typedef __attribute__((address_space(3))) float lds_f;
+        unsigned pa[4][3];
         float rr[4][9];
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) {
           const int e = e0 + ee, row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-          p0[ee] = img + row * WC + 4 * ((col >> 2) ^ (row & 15)) + (col & 3);     // output k at p0 + k * 64 * 64
+          pa[ee][0] = lds0 + 4u * (unsigned)(row * WC + 4 * ((col >> 2) ^ (row & 15)) + (col & 3));
+          pa[ee][1] = pa[ee][0] + 4u * 4 * (WT * WC);
+          pa[ee][2] = pa[ee][0] + 4u * 8 * (WT * WC);
+          asm volatile("" : "+v"(pa[ee][1]), "+v"(pa[ee][2]));
 #pragma unroll
-          for (int k = 0; k < 9; ++k) rr[ee][k] = decltype(with_res)::value ? p0[ee][k * (WT * WC)] : 0.f;
+          for (int k = 0; k < 9; ++k)
+            rr[ee][k] = decltype(with_res)::value ? *((lds_f*)(size_t)pa[ee][k >> 2] + (k & 3) * (WT * WC)) : 0.f;
         }
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee)
@@ -653,7 +661,7 @@ __device__ __forceinline__ void wino_wg(
           for (int k = 0; k < 9; ++k) {
             float v = o[k][e0 + ee] * sc + sh + rr[ee][k];
             v = fmaxf(v, relu_lo);
-            p0[ee][k * (WT * WC)] = v;
+            *((lds_f*)(size_t)pa[ee][k >> 2] + (k & 3) * (WT * WC)) = v;
           }
       }
     };
