@@ -192,6 +192,7 @@ def load():
         "agz_debug_math": (i32, [E, i32, f64p, f64p, i32, f64p]),
         "agz_debug_counters": (i32, [E, C.POINTER(C.c_uint64), i32]),
         "agz_debug_set_stagger": (i32, [E, i32]),
+        "agz_debug_live_record": (i32, [E, i32, i32, P(u64), i32p, i32p, f32p, f32p]),
         "agz_debug_mfma_sustained": (i32, [E, i32, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():

@@ -251,6 +251,46 @@ class NodeView:
         return self.child_W / (np.float32(1) + self.child_N)
 
     @property
+    def child_U(self):                        # mcts.jl:91-92: c_puct (Float64) x Float32 sqrt x prior / (1 + N)
+        c = float(self._p.engine.cfg.c_puct)
+        return c * np.sqrt(np.float32(1) + np.float32(self.N)) * self.child_prior / (np.float32(1) + self.child_N)
+
+    def __eq__(self, other):
+        return isinstance(other, NodeView) and other._p is self._p and other.id == self.id
+
+    def __hash__(self):
+        return hash((id(self._p), self.id))
+
+    # ---- the node-level operations test/test_mcts.jl:2-5 imports, one agz_tree_* call each
+    def select_leaf(self):                    # mcts.jl:108-138
+        return NodeView(self._p, self._p.engine.select_leaf(0, self.id))
+
+    def maybe_add_child(self, f):             # mcts.jl:140-149 (f: 0-based flat move, N*N = pass)
+        return NodeView(self._p, self._p.engine.maybe_add_child(0, self.id, int(f)))
+
+    def add_virtual_loss(self, up_to):        # mcts.jl:151-163
+        self._p.engine.add_virtual_loss(0, self.id, up_to.id)
+
+    def revert_virtual_loss(self, up_to):     # mcts.jl:165-177
+        self._p.engine.revert_virtual_loss(0, self.id, up_to.id)
+
+    def incorporate_results(self, move_probs, value, up_to):      # mcts.jl:187-214
+        e = self._p.engine
+        st = e.incorporate_results(0, self.id, np.asarray(move_probs, np.float32), float(value), up_to.id)
+        if st in (_lib.ASSERT_DONE_NODE, _lib.BAD_SHAPE):
+            raise AssertionError(e.L.agz_last_error(e.h).decode())      # mcts.jl:190,196
+        e._ck(st)
+
+    def inject_noise(self):                   # mcts.jl:232-239
+        self._p.engine.inject_noise(0, self.id)
+
+    def set_N(self, value):                   # mcts.jl:99
+        self._p.engine.node_set_N(0, self.id, float(value))
+
+    def is_done(self):                        # mcts.jl:227-229
+        return bool(self._p.engine.is_done(0, self.id))
+
+    @property
     def children(self):
         ch = self._p.engine.node_children(0, self.id)
         return {int(a): NodeView(self._p, int(c)) for a, c in enumerate(ch) if c >= 0}
@@ -348,6 +388,15 @@ class MCTSPlayer:
             return False
         self._moves.append(c)
         return True
+
+    def get_position(self):                   # mcts_play.jl:141-142
+        return self.root.position
+
+    def suggest_move(self):                   # mcts_play.jl:144-151
+        current_readouts = self.root.N
+        while self.root.N < current_readouts + self.num_readouts:
+            self.tree_search()
+        return self.pick_move()
 
     def should_resign(self):                  # mcts_play.jl:124
         return bool(self.engine.should_resign(0))

@@ -558,6 +558,10 @@ int32_t agz_debug_counters(agz_engine* e, uint64_t* out, int32_t cap) {
   (void)guard(e, [&](agz::Engine& E) { n = E.debug_counters(out, cap); });
   return n;
 }
+agz_status agz_debug_live_record(agz_engine* e, int32_t g, int32_t k, uint64_t* game_id_out, int32_t* num_moves_out,
+                                 int32_t* move_out, float* pi_out, float* q_out) {
+  return guard(e, [&](agz::Engine& E) { E.debug_live_record(g, k, game_id_out, num_moves_out, move_out, pi_out, q_out); });
+}
 agz_status agz_debug_set_stagger(agz_engine* e, int32_t moves) {
   return guard(e, [&](agz::Engine& E) { E.debug_set_stagger(moves); });
 }

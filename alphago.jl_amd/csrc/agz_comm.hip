@@ -88,7 +88,7 @@ struct Comm {
   int rank = 0, world = 1;
   Engine* engine = nullptr;
   DevBuf<int64_t> d_counts;     // [1 + world][2]: mine, then everybody's {records, bytes}
-  DevBuf<uint8_t> d_recv;
+  DevBuf<uint8_t> d_pack, d_recv;   // this rank's packed records (send) / everybody's chunks (receive)
 };
 
 void comm_unique_id(uint8_t* out) {
@@ -147,14 +147,22 @@ int64_t comm_allgather_records(Engine& E, Comm* c) {
   AGZ_REQUIRE(c->engine == &E, AGZ_BAD_ARGUMENT, "communicator belongs to another engine");
   hipStream_t s = E.stream();
   const int W = c->world;
-  // 1. what this rank has to send (headers only: the payload is packed straight into its slot of the receive buffer
-  //    once the stride is known -- the in-place form of ncclAllGather, no send buffer and no regrow-and-copy)
+  // 1. everything that can fail on ONE rank happens before the first collective: this rank's unsent records are
+  //    packed into its own send buffer now, and a failure is announced as {-1, status} in the count collective, so
+  //    that every rank leaves the call together (a pack that failed between the two collectives left the
+  //    other ranks waiting in the payload all-gather)
   const int64_t first = E.records_exchanged();
   int64_t mine[2] = {0, 0};
   std::string my_error;
   try {
     mine[0] = std::max<int64_t>(0, E.records_count() - first);
     mine[1] = E.records_packed_size(first);
+    if (mine[0] > 0) {
+      c->d_pack.ensure((size_t)((mine[1] + 255) & ~(int64_t)255));
+      int64_t nb = 0;
+      const int64_t nrec = E.pack_records_device(c->d_pack.p, (int64_t)c->d_pack.n, &nb, first);
+      AGZ_REQUIRE(nrec == mine[0] && nb == mine[1], AGZ_RCCL_ERROR, "records changed during the exchange");
+    }
   } catch (const Error& x) {
     mine[0] = -1;
     mine[1] = x.status;
@@ -166,16 +174,32 @@ int64_t comm_allgather_records(Engine& E, Comm* c) {
   std::vector<int64_t> counts((size_t)2 * W);
   AGZ_HIP(hipMemcpyAsync(counts.data(), c->d_counts.p + 2, sizeof(int64_t) * counts.size(), hipMemcpyDeviceToHost, s));
   AGZ_HIP(hipStreamSynchronize(s));
-  if (mine[0] == -1) throw Error((agz_status)mine[1], my_error);
   int64_t total = 0;
-  const int64_t stride = gather_plan(counts.data(), W, &total);
+  // (a rank that failed reports AGZ_RCCL_ERROR like its peers -- the plan names it -- with its own reason appended)
+  int64_t stride = 0;
+  try {
+    stride = gather_plan(counts.data(), W, &total);
+  } catch (const Error& x) {
+    if (mine[0] == -1) throw Error(x.status, std::string(x.what()) + "; this rank: " + my_error);
+    throw;
+  }
   if (total == 0) return 0;
-  // 3. payload, padded to the largest rank (the pad bytes are never read: step 4 stops at each rank's count)
+  // 3. payload, padded to the largest rank (the pad bytes are never read: step 4 stops at each rank's count).  The
+  //    send buffer must be readable up to the stride: grow it around what was packed if another rank's chunk is larger
+  if (c->d_pack.n < (size_t)stride) {
+    DevBuf<uint8_t> bigger;
+    bigger.alloc((size_t)stride);
+    if (mine[1] > 0) AGZ_HIP(hipMemcpyAsync(bigger.p, c->d_pack.p, (size_t)mine[1], hipMemcpyDeviceToDevice, s));
+    AGZ_HIP(hipStreamSynchronize(s));
+    std::swap(bigger.p, c->d_pack.p);
+    std::swap(bigger.n, c->d_pack.n);
+  }
   c->d_recv.ensure((size_t)stride * W);        // grow-only; nothing of an earlier call is kept in it
-  int64_t nb = 0;
-  const int64_t nrec = E.pack_records_device(c->d_recv.p + (size_t)stride * c->rank, stride, &nb, first);
-  AGZ_REQUIRE(nrec == mine[0] && nb == mine[1], AGZ_RCCL_ERROR, "records changed during the exchange");
-  AGZ_RCCL(rccl().AllGather(c->d_recv.p + (size_t)stride * c->rank, c->d_recv.p, (size_t)stride, ncclUint8, c->comm, s));
+  AGZ_RCCL(rccl().AllGather(c->d_pack.p, c->d_recv.p, (size_t)stride, ncclUint8, c->comm, s));
+  AGZ_HIP(hipStreamSynchronize(s));            // the collective has completed on this rank: its records are everybody's
+  // the watermark moves with the collective, not with the local ingest: a rank whose ingest fails must not send the
+  // same games again (its peers have filed them)
+  E.records_mark_exchanged(first + mine[0]);
   // 4 + 5. index on the device, compact into the arena
   std::vector<int64_t> coff((size_t)W), cbytes((size_t)W), cnrec((size_t)W);
   for (int r = 0; r < W; ++r) {
@@ -183,9 +207,7 @@ int64_t comm_allgather_records(Engine& E, Comm* c) {
     cnrec[r] = counts[2 * r];
     cbytes[r] = counts[2 * r + 1];
   }
-  const int64_t added = E.replay_ingest_chunks(c->d_recv.p, coff, cbytes, cnrec);
-  E.records_mark_exchanged(first + nrec);
-  return added;
+  return E.replay_ingest_chunks(c->d_recv.p, coff, cbytes, cnrec);
 }
 
 // rank `root`'s parameters overwrite every other rank's replica (one flat f32 broadcast, 12-24 M parameters)

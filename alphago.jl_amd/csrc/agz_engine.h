@@ -31,6 +31,7 @@ class Engine {
   void step(int nsteps);
   void stats(agz_stats* out);
   int debug_counters(uint64_t* out, int cap);
+  void debug_live_record(int g, int k, uint64_t* game_id, int32_t* num_moves, int32_t* move, float* pi, float* q);
   void debug_set_stagger(int moves);
   int select_external();
   void leaf_features_external(float* feats_out);
@@ -148,6 +149,7 @@ class Engine {
   std::vector<int64_t> rp_off_;
   std::vector<agz_game_header> rp_hdr_;
   int64_t rec_sent_ = 0;
+  bool stepped_ = false;           // a step has run since the last start(): agz_debug_set_stagger is refused
 };
 
 // RCCL exchange (agz_comm.hip)

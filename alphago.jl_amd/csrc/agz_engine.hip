@@ -399,6 +399,10 @@ static void validate(const agz_config& c) {
   AGZ_REQUIRE(c.parallel_readouts >= 1 && c.parallel_readouts <= kMaxPar, AGZ_BAD_ARGUMENT,
               "parallel_readouts %d not in 1..%d", c.parallel_readouts, kMaxPar);
   AGZ_REQUIRE(!c.arena_mode || c.games % 2 == 0, AGZ_BAD_ARGUMENT, "arena_mode needs an even number of slots");
+  // reserved1 was `stagger_moves` until round 2 (now agz_debug_set_stagger): an old-ABI caller that still sets it must
+  // hear about it instead of silently getting un-staggered games
+  AGZ_REQUIRE(c.reserved1 == 0 && c.reserved0 == 0.f, AGZ_BAD_ARGUMENT,
+              "agz_config.reserved0/reserved1 must be 0 (reserved1 was stagger_moves: use agz_debug_set_stagger)");
 }
 
 Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
@@ -456,7 +460,13 @@ Engine::~Engine() {
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-void Engine::sync() { AGZ_HIP(hipStreamSynchronize(stream_)); }
+void Engine::sync() {
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  // an error word a persistent tower launch raised is reported by the first synchronising call behind it, not only by
+  // the next persistent forward
+  net_->check_async_error();
+  if (net2_) net2_->check_async_error();
+}
 
 void Engine::net_select(int which) {
   AGZ_REQUIRE(which == 0 || (which == 1 && net2_), AGZ_BAD_ARGUMENT,
@@ -467,6 +477,7 @@ void Engine::net_select(int which) {
 void Engine::start(int64_t total_games) {
   V_.total_games = total_games;
   rec_sent_ = 0;
+  stepped_ = false;
   AGZ_HIP(hipMemsetAsync(V_.counters, 0, sizeof(unsigned long long) * CT_COUNT, stream_));
   AGZ_HIP(hipMemsetAsync(V_.ar_hdr, 0, sizeof(int32_t) * 5 * (V_.games / 2 + 1), stream_));
   std::vector<GameState> gs(V_.games);
@@ -479,6 +490,7 @@ void Engine::start(int64_t total_games) {
 void Engine::step(int nsteps) {
   AGZ_REQUIRE(!cfg_.external_network, AGZ_BAD_ARGUMENT,
               "engine was created with external_network=1: use select/incorporate");
+  stepped_ = stepped_ || nsteps > 0;
   for (int s = 0; s < nsteps; ++s) {
     hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
     hipLaunchKernelGGL(k_expand, dim3(V_.games * (kMaxPend / 2)), dim3(kWave), 0, stream_, V_);
@@ -498,6 +510,7 @@ void Engine::step(int nsteps) {
 }
 
 int Engine::select_external() {
+  stepped_ = true;
   hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
   hipLaunchKernelGGL(k_expand, dim3(V_.games * (kMaxPend / 2)), dim3(kWave), 0, stream_, V_);
   hipLaunchKernelGGL(cfg_.arena_mode ? k_scan_arena : k_scan, dim3(1), dim3(256), 0, stream_, V_);
@@ -547,7 +560,26 @@ void Engine::incorporate_external(const float* pi, const float* v) {
 
 void Engine::debug_set_stagger(int moves) {
   AGZ_REQUIRE(moves >= 0 && !cfg_.arena_mode, AGZ_BAD_ARGUMENT, "stagger: >= 0 moves, not in arena_mode");
+  AGZ_REQUIRE(!stepped_, AGZ_BAD_ARGUMENT, "stagger: set it before the first step of a run (before or right after agz_selfplay_start)");
   V_.stagger = moves;            // the View travels to the kernels by value: effective from the next launch
+}
+
+void Engine::debug_live_record(int g, int k, uint64_t* game_id, int32_t* num_moves, int32_t* move, float* pi, float* q) {
+  AGZ_REQUIRE(g >= 0 && g < V_.games, AGZ_BAD_ARGUMENT, "slot %d of %d", g, V_.games);
+  GameState G;
+  AGZ_HIP(hipMemcpyAsync(&G, V_.gs + g, sizeof(G), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  if (game_id) *game_id = G.game_id;
+  if (num_moves) *num_moves = G.nqs;
+  if (k < 0) return;
+  AGZ_REQUIRE(k < G.nqs, AGZ_BAD_ARGUMENT, "slot %d has recorded %d moves", g, G.nqs);
+  const long at = (long)g * V_.max_game_length + k;
+  int16_t m = 0;
+  AGZ_HIP(hipMemcpyAsync(&m, V_.rec_moves + at, sizeof(m), hipMemcpyDeviceToHost, stream_));
+  if (q) AGZ_HIP(hipMemcpyAsync(q, V_.rec_q + at, sizeof(float), hipMemcpyDeviceToHost, stream_));
+  if (pi) AGZ_HIP(hipMemcpyAsync(pi, V_.rec_pi + at * V_.A, sizeof(float) * V_.A, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  if (move) *move = m;
 }
 
 int Engine::debug_counters(uint64_t* out, int cap) {
@@ -564,6 +596,8 @@ void Engine::stats(agz_stats* out) {
   std::vector<GameState> gs(V_.games);
   AGZ_HIP(hipMemcpyAsync(gs.data(), V_.gs, sizeof(GameState) * gs.size(), hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
+  net_->check_async_error();
+  if (net2_) net2_->check_async_error();
   std::memset(out, 0, sizeof(*out));
   out->steps = (int64_t)c[CT_STEPS];
   out->positions = (int64_t)c[CT_POSITIONS];
@@ -588,6 +622,8 @@ int64_t Engine::records_count() {
   unsigned long long f = 0;
   AGZ_HIP(hipMemcpyAsync(&f, V_.counters + CT_RECORDED, sizeof(f), hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
+  net_->check_async_error();
+  if (net2_) net2_->check_async_error();
   return (int64_t)std::min<unsigned long long>(f, (unsigned long long)V_.fin_cap);
 }
 
@@ -1016,6 +1052,7 @@ void Engine::net_forward_positions(const int8_t* boards, const int8_t* deltas, c
   AGZ_HIP(hipMemcpyAsync(pi_out, s_f32b_.p, sizeof(float) * (size_t)B * V_.A, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipMemcpyAsync(v_out, s_f32b_.p + (size_t)B * V_.A, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
+  net().check_async_error();      // a persistent tower launch that gave up: these outputs are garbage, say so now
 }
 
 void Engine::net_forward_features(const float* feats, int B, float* pi_out, float* v_out) {
@@ -1033,6 +1070,7 @@ void Engine::net_forward_features(const float* feats, int B, float* pi_out, floa
   AGZ_HIP(hipMemcpyAsync(pi_out, s_f32b_.p, sizeof(float) * (size_t)B * V_.A, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipMemcpyAsync(v_out, s_f32b_.p + (size_t)B * V_.A, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
+  net().check_async_error();      // a persistent tower launch that gave up: these outputs are garbage, say so now
 }
 
 // random stone features (not zeros: DVFS makes zero-filled operands look faster than real data)

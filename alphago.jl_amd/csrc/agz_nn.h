@@ -54,6 +54,10 @@ class Net {
   // (whole-board tile blocks, 256 CUs with 32 resident workgroups per XCD); same arithmetic, same bits.  Off by
   // default: it needs 3.7 % fewer cycles and the clock comes down by as much -- same wall time.
   void set_tower_persistent(bool on) { tower_persistent_ = on; }
+  // Throws if a persistent tower launch that has completed raised its scheduler's error word (its outputs were
+  // garbage).  Called by every forward and by the engine's synchronising calls; the caller has synchronised the stream,
+  // or accepts hearing about the error one call later.
+  void check_async_error();
   bool tower_persistent() const { return tower_persistent_; }
   // tower arithmetic: 0 = exact f32 (default), 1 = fp16 operands / f32 accumulate (agz_conv16.hip)
   // 2 = exact-f32 network with the Winograd operands carried as two f16 halves (agz_wino.hip, split form)

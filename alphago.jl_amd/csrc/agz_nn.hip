@@ -639,7 +639,18 @@ void launch_conv3x3_direct_taps(const float* x, const float* wt, const float* on
   hipLaunchKernelGGL(k_sum_taps, dim3(g), dim3(256), 0, s, (const float*)part, stride, shift, y, d_count, N * N);
 }
 
+void Net::check_async_error() {
+  if (tower_err_ && *tower_err_) {
+    const int err = *tower_err_;
+    *tower_err_ = 0;
+    AGZ_REQUIRE(false, AGZ_HIP_ERROR,
+                "the persistent tower kernel of an earlier forward gave up (scheduler error word %d: 1 = more than 32 "
+                "workgroups on one XCD, 2 = a tile block's producer never arrived); its outputs were garbage", err);
+  }
+}
+
 void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi, float* d_v) {
+  check_async_error();      // (whichever launch form this forward takes)
   pack();
   reserve(bcap);
   const int grid = conv_grid(bcap, P_);
@@ -715,13 +726,6 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       const bool persistent = tower_persistent_ && !dense && stem_wino && wino_tower_supported(stream_);
       if (persistent) {
         // the same layers as the loop below, as a table for ONE persistent launch (k_wino_tower)
-        if (tower_err_ && *tower_err_) {
-          const int err = *tower_err_;
-          *tower_err_ = 0;
-          AGZ_REQUIRE(false, AGZ_HIP_ERROR,
-                      "the persistent tower kernel of an earlier forward gave up (scheduler error word %d: 1 = more than 32 "
-                      "workgroups on one XCD, 2 = a tile block's producer never arrived); its outputs were garbage", err);
-        }
         const int nl = 2 * tower_;
         std::vector<WinoTowerLayer> tab(nl);
         float *pa = a, *pb = b, *vc = vcur, *vn = vnxt;

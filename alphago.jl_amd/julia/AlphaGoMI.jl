@@ -19,7 +19,11 @@ module AlphaGoMI
 
 export GoEnv, Position, NeuralNet, MCTSPlayer, selfplay, extract_data, initialize_game!,
        tree_search!, pick_move, play_move!, should_resign, is_done, set_result!, all_legal_moves,
-       score, result, IllegalMove, to_flat, from_flat
+       score, result, IllegalMove, to_flat, from_flat,
+       # the node-level surface test/test_mcts.jl:2-5 and test/test_mcts_player.jl:3-6 import
+       MCTSNode, select_leaf, maybe_add_child!, add_virtual_loss!, revert_virtual_loss!,
+       incorporate_results!, inject_noise!, child_action_score, child_Q, child_U, child_N, child_W,
+       child_prior, N, Q, set_N!, suggest_move, get_position
 
 const libagz = get(ENV, "AGZ_LIB", joinpath(@__DIR__, "..", "libagz.so"))
 
@@ -359,6 +363,121 @@ function play_move!(p::MCTSPlayer, c)                                           
     return false
   end
   true
+end
+
+# ------------------------------------------------------------------ MCTSNode (node-level surface)
+# The reference's tests drive single nodes (test/test_mcts.jl:2-5, test/test_mcts_player.jl:3-6): an MCTSNode here is
+# a handle -- the player whose tree it lives in and the slot-local node id of include/agz.h -- and every function
+# below is one agz_tree_* call.  `player.root` reads as in the reference (a property, below).
+struct MCTSNode
+  player::MCTSPlayer
+  id::Int32
+end
+Base.getproperty(p::MCTSPlayer, s::Symbol) = s === :root ? MCTSNode(p, root(p)) : getfield(p, s)
+Base.:(==)(a::MCTSNode, b::MCTSNode) = a.player === b.player && a.id == b.id
+
+node_info(x::MCTSNode) = node_info(x.player, x.id)
+N(x::MCTSNode) = node_info(x).N                                                 # mcts.jl:98-100
+Q(x::MCTSNode) = node_info(x).Q                                                 # mcts.jl:94
+function node_floats(x::MCTSNode, field::Integer)
+  e = x.player.engine
+  out = zeros(Float32, x.player.env.action_space)
+  check(e, ccall((:agz_tree_node_floats, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float32}),
+                 e.handle, 0, x.id, field, out))
+  out
+end
+child_N(x::MCTSNode) = node_floats(x, 0)
+child_W(x::MCTSNode) = node_floats(x, 1)
+child_prior(x::MCTSNode) = node_floats(x, 2)
+child_Q(x::MCTSNode) = child_W(x) ./ (1 .+ child_N(x))                          # mcts.jl:89
+# mcts.jl:91-92, in the reference's own mixed precision (c_puct is Float64, the square root is Float32's)
+child_U(x::MCTSNode) = (x.player.engine.cfg.c_puct * √(1 .+ N(x)) * child_prior(x) ./ (1 .+ child_N(x)))
+function child_action_score(x::MCTSNode)                                         # mcts.jl:86-87 (Float64 scores)
+  e = x.player.engine
+  out = zeros(Float64, x.player.env.action_space)
+  check(e, ccall((:agz_tree_node_scores, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}),
+                 e.handle, 0, x.id, out))
+  out
+end
+function set_N!(x::MCTSNode, value)                                             # mcts.jl:99
+  e = x.player.engine
+  check(e, ccall((:agz_tree_node_set_N, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Float32),
+                 e.handle, 0, x.id, Float32(value)))
+  value
+end
+
+function select_leaf(x::MCTSNode)                                               # mcts.jl:108-138
+  e = x.player.engine
+  leaf = Ref{Int32}(0)
+  check(e, ccall((:agz_tree_select_leaf, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}),
+                 e.handle, 0, x.id, leaf))
+  MCTSNode(x.player, leaf[])
+end
+function maybe_add_child!(x::MCTSNode, f::Integer)                              # mcts.jl:140-149; f is 1-based
+  e = x.player.engine
+  child = Ref{Int32}(0)
+  check(e, ccall((:agz_tree_maybe_add_child, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Ref{Int32}),
+                 e.handle, 0, x.id, f - 1, child))
+  MCTSNode(x.player, child[])
+end
+# `up_to` is the node the walk towards the root stops at (mcts.jl:151-177); the tests pass `player.root`
+function add_virtual_loss!(x::MCTSNode, up_to::MCTSNode)
+  e = x.player.engine
+  check(e, ccall((:agz_tree_add_virtual_loss, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Int32),
+                 e.handle, 0, x.id, up_to.id))
+end
+function revert_virtual_loss!(x::MCTSNode, up_to::MCTSNode)
+  e = x.player.engine
+  check(e, ccall((:agz_tree_revert_virtual_loss, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Int32),
+                 e.handle, 0, x.id, up_to.id))
+end
+function incorporate_results!(x::MCTSNode, move_probs, value, up_to::MCTSNode)  # mcts.jl:187-214
+  e = x.player.engine
+  probs = Float32.(vec(move_probs))
+  check(e, ccall((:agz_tree_incorporate, libagz), Int32,
+                 (Ptr{Cvoid}, Int32, Int32, Ptr{Float32}, Int32, Float32, Int32),
+                 e.handle, 0, x.id, probs, length(probs), Float32(value), up_to.id))
+end
+function inject_noise!(x::MCTSNode)                                             # mcts.jl:232-239
+  e = x.player.engine
+  check(e, ccall((:agz_tree_inject_noise, libagz), Int32, (Ptr{Cvoid}, Int32, Int32), e.handle, 0, x.id))
+end
+function is_done(x::MCTSNode)                                                   # mcts.jl:227-229
+  e = x.player.engine
+  r = Ref{Int32}(0)
+  check(e, ccall((:agz_tree_is_done, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}), e.handle, 0, x.id, r))
+  r[] != 0
+end
+function children(x::MCTSNode)                                                  # Dict(flat move => child), mcts.jl:51
+  e = x.player.engine
+  ids = zeros(Int32, x.player.env.action_space)
+  check(e, ccall((:agz_tree_node_children, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}),
+                 e.handle, 0, x.id, ids))
+  Dict(f => MCTSNode(x.player, ids[f]) for f in eachindex(ids) if ids[f] >= 0)
+end
+function position(x::MCTSNode)                                                  # the node's GoPosition, mcts.jl:44
+  p = x.player; e = p.engine; env = p.env
+  info = node_info(x)
+  board = zeros(Int8, env.N, env.N)
+  check(e, ccall((:agz_tree_node_board, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Int8}),
+                 e.handle, 0, x.id, board))
+  pos = Position(env)
+  pos.board = board; pos.n = info.pos.n; pos.komi = info.pos.komi
+  pos.caps = (Int(info.pos.caps_black), Int(info.pos.caps_white))
+  pos.ko = info.pos.ko < 0 ? nothing : from_flat(info.pos.ko + 1, env)
+  pos.to_play = info.pos.to_play
+  pos.done = info.done != 0
+  pos
+end
+
+get_position(p::MCTSPlayer) = position(p.root)                                  # mcts_play.jl:141-142
+
+function suggest_move(p::MCTSPlayer)                                            # mcts_play.jl:144-151
+  current_readouts = N(p)
+  while N(p) < current_readouts + p.num_readouts
+    tree_search!(p)
+  end
+  pick_move(p)
 end
 
 function should_resign(p::MCTSPlayer)                                           # mcts_play.jl:124

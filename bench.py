@@ -55,6 +55,102 @@ def pmc_traffic(rows_per_launch, N, precision="f32"):
     return None, None
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU, sampled from the amdgpu hwmon files while a timed region runs.
+
+    The f32 MFMA layer is power-limited: its `frac` of the nominal peak only means something next to the
+    clock and the watts the board actually ran at, so the line carries them.  Sources, first that works:
+    hwmon power1_average / power1_input (microwatts) and freq1_input (Hz, sclk) under the device's sysfs node; the
+    amdsmi Python module; nothing (the object then says so).  ~20 samples per second on a daemon thread: no GPU work."""
+
+    def __init__(self, device_index=0):
+        import glob
+        import threading
+        self.samples, self._stop, self._th = [], threading.Event(), None
+        self.source, self._pw, self._fq, self._smi = None, None, None, None
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+            if hw:
+                cards.append((os.path.realpath(dev), hw[0]))
+        want = None
+        try:      # match the torch device by PCI address where the build exposes it
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:
+            pass
+        pick = [c for c in cards if want and want in c[0]] or cards[device_index:device_index + 1] or cards[:1]
+        if pick:
+            hw = pick[0][1]
+            for name in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(hw, name)):
+                    self._pw = os.path.join(hw, name)
+                    break
+            if os.path.exists(os.path.join(hw, "freq1_input")):
+                self._fq = os.path.join(hw, "freq1_input")
+            if self._pw or self._fq:
+                self.source = f"sysfs {hw} ({os.path.basename(self._pw) if self._pw else '-'}, {'freq1_input' if self._fq else '-'})"
+        if self.source is None:
+            try:
+                import amdsmi
+                amdsmi.amdsmi_init()
+                self._smi = (amdsmi, amdsmi.amdsmi_get_processor_handles()[device_index])
+                self.source = "amdsmi"
+            except Exception:
+                self._smi = None
+
+    def _read(self):
+        w = mhz = None
+        try:
+            if self._pw:
+                w = int(open(self._pw).read()) * 1e-6
+            if self._fq:
+                mhz = int(open(self._fq).read()) * 1e-6
+            if self._smi:
+                m, h = self._smi
+                pw = m.amdsmi_get_power_info(h)
+                w = float(pw.get("current_socket_power") or pw.get("average_socket_power") or 0) or None
+                ck = m.amdsmi_get_clock_info(h, m.AmdSmiClkType.GFX)
+                mhz = float(ck.get("clk") or ck.get("cur_clk") or 0) or None
+        except Exception:
+            pass
+        return w, mhz
+
+    def start(self):
+        import threading
+        if self.source is None:
+            return self
+        self.samples = []
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._read())
+                self._stop.wait(0.05)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+        return self
+
+    def stop(self):
+        if self._th is not None:
+            self._stop.set()
+            self._th.join(timeout=2.0)
+            self._th = None
+        ws = [w for w, _ in self.samples if w]
+        fs = [f for _, f in self.samples if f]
+        if self.source is None:
+            return {"source": None, "note": "no hwmon power/clock file and no amdsmi module on this host"}
+        return {"source": self.source, "samples": len(self.samples),
+                "socket_power_w": {"mean": sum(ws) / len(ws), "max": max(ws)} if ws else None,
+                "sclk_mhz": {"mean": sum(fs) / len(fs), "min": min(fs), "max": max(fs)} if fs else None}
+
+
 def cpu_baseline(N, tower, readouts, seconds):
     """oracle selfplay on the host cores; returns the cpu_baseline object"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -144,11 +240,15 @@ def main():
     ap.add_argument("--no-sustained", action="store_true", help="skip the 0.4 s sustained-MFMA-rate measurement behind the timed region")
     ap.add_argument("--no-alt-precision", action="store_true",
                     help="skip the extra (untimed for `value`) leg that repeats the K steps with --precision f32s")
-    ap.add_argument("--generation", type=int, default=0, metavar="G",
+    ap.add_argument("--generation", type=int, default=None, metavar="G",
                     help="after the timed K steps keep playing, untimed for `value`: a warm-up until G games have ended "
                          "naturally, then a window until G more have; the line gains a `generation` object with SURVEY.md 8d's "
                          "generation rate (sum of position.n of the games that ended in the window / wall time) next to the "
-                         "steady-state rate of the same window (0 = off; 256 takes about two minutes)")
+                         "steady-state rate of the same window.  Default: 128 on the headline workload at N = 1 (0 = off), "
+                         "bounded by --generation-seconds")
+    ap.add_argument("--generation-seconds", type=float, default=120.0,
+                    help="hard cap on the generation leg (two thirds for the warm-up, one third for the window); a leg the cap "
+                         "cut short reports what it saw and says so")
     ap.add_argument("--single-device-test", action="store_true",
                     help="testing only: every rank uses cuda:0 and gloo, to exercise the multi-rank code path on a 1-GPU box")
     args = ap.parse_args()
@@ -160,6 +260,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.generation is None:      # SURVEY.md 8d's definition rides along on the headline line
+        headline = (args.board, args.tower, args.readouts, args.games, args.precision) == (9, 10, 400, 1024, "f32")
+        args.generation = 128 if (world == 1 and headline and args.stagger > 0) else 0
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
@@ -205,12 +308,16 @@ def main():
     eng.sync()
     s0 = eng.stats()
     eng.profile_conv(True)
+    sampler = PowerSampler(local_rank) if rank == 0 else None
     barrier()
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     eng.step(args.steps)
     eng.sync()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    power = sampler.stop() if sampler else None
     barrier()
     conv_ms, conv_flop, conv_n = eng.profile_conv_read()
     eng.profile_conv(False)
@@ -260,20 +367,24 @@ def main():
     if args.generation > 0 and world == 1:
         G = args.generation
         import numpy as np
+        cap_warm, cap_win = args.generation_seconds * 2.0 / 3.0, args.generation_seconds / 3.0
         g0 = eng.stats()["games_finished"]
         tw = time.perf_counter()
-        while eng.stats()["games_finished"] - g0 < G and time.perf_counter() - tw < 900.0:
+        while eng.stats()["games_finished"] - g0 < G and time.perf_counter() - tw < cap_warm:
             eng.step(25)
         warm_s = time.perf_counter() - tw
+        warm_games = eng.stats()["games_finished"] - g0
         eng.records_clear()
         q0 = eng.stats()
+        gsampler = PowerSampler(local_rank).start()
         tg0 = time.perf_counter()
         while True:
             eng.step(25)
             q1 = eng.stats()                       # synchronises
-            if q1["games_finished"] - q0["games_finished"] >= G or time.perf_counter() - tg0 > 900.0:
+            if q1["games_finished"] - q0["games_finished"] >= G or time.perf_counter() - tg0 > cap_win:
                 break
         wall = time.perf_counter() - tg0
+        gpower = gsampler.stop()
         recs = eng.records()
         nm = np.array([r["num_moves"] for r in recs], np.int64)
         gd = {k: q1[k] - q0[k] for k in ("positions", "evals", "games_finished", "resigned_games", "steps", "terminal_visits")}
@@ -287,6 +398,9 @@ def main():
             "game_length": {"mean": float(nm.mean()), "min": int(nm.min()), "max": int(nm.max())} if len(nm) else None,
             "evals_per_position": gd["evals"] / max(gd["positions"], 1), "terminal_visits": gd["terminal_visits"],
             "batch_fill": gd["evals"] / max(gd["steps"] * 8 * args.games, 1), "warmup_s": warm_s,
+            "warmup_games_finished": warm_games, "requested_games": G,
+            "capped": bool(warm_games < G or gd["games_finished"] < G), "cap_seconds": args.generation_seconds,
+            "power": gpower,
             "note": "generation_rate counts the moves of the games that ENDED in the window (8d), steady_state_rate the moves "
                     "PLAYED in it (bench.py's `value` definition); they differ while the population of game ages is not stationary",
         }
@@ -297,8 +411,9 @@ def main():
     if dist is not None:
         # the timed region of the headline config sees no game end (2 of ~76 moves per game); the exchange needs
         # finished games: keep playing, untimed, until this rank has some (bounded)
-        for _ in range(16):
-            if eng.records_count() >= 4:
+        # (>= 16 games per rank, so that the payload collective moves unequal, non-trivial chunks: VERDICT r3 #6)
+        for _ in range(60):
+            if eng.records_count() >= 16:
                 break
             eng.step(50)
         # RCCL prints a version banner on stdout when a communicator is created; stdout must carry exactly one
@@ -437,7 +552,14 @@ def main():
             "end_to_end_algorithmic_tflops": value * fpos / world / 1e12,          # positions/s x F_position
             "end_to_end_executed_mfma_frac": value * fpos * wino_ratio / (world * peak * 1e12),
             "roofline": roofline,
+            "power": power,        # socket power and shader clock over the timed region (PowerSampler)
         }
+        if power and power.get("sclk_mhz") and not f16 and not f32s and exe_tf is not None:
+            # what the nominal peak becomes at the clock the timed region actually ran at (the peak assumes 2.4 GHz)
+            mhz = power["sclk_mhz"]["mean"]
+            roofline["at_measured_clock"] = {"sclk_mhz": mhz, "peak": peak * mhz / 2400.0,
+                                             "frac": exe_tf / (peak * mhz / 2400.0), "unit": "TFLOP/s",
+                                             "note": "peak scaled from the 2.4 GHz nominal clock to the mean sampled sclk"}
         if generation is not None:
             out["generation"] = generation
         if exchange is not None:

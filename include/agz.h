@@ -298,12 +298,15 @@ agz_status agz_comm_unique_id(uint8_t* id_out /* [AGZ_COMM_ID_BYTES] */);
 agz_status agz_comm_create(agz_engine* e, int32_t rank, int32_t world, const uint8_t* id, agz_comm** out);
 void agz_comm_destroy(agz_comm* c);
 /* all-gather the finished records of every rank (what agz_records_* shows on each) into THIS rank's replay
- * arena, rank 0's games first: count exchange + one padded in-place ncclAllGather, device to device.  Records
- * this call has already filed are not sent again (a second call without new finished games adds nothing);
+ * arena, rank 0's games first: this rank's unsent records are packed on the device, then a count exchange and one
+ * padded ncclAllGather, device to device.  Records a completed payload collective has carried are not sent again,
+ * whether or not this rank's own ingest then succeeded (a second call without new finished games adds nothing);
  * agz_records_clear empties the record ring and resets that mark.  comm == NULL: single-GPU run, files the
  * engine's own records.  added_out (may be NULL) = games appended.  Collective: every rank of the
- * communicator must call it; a rank that fails before the payload collective announces that in the count
- * collective and EVERY rank returns AGZ_RCCL_ERROR (nobody is left waiting in ncclAllGather). */
+ * communicator must call it.  Everything that can fail on one rank alone (counting, packing) happens BEFORE the
+ * first collective; such a rank announces {-1, its status} in the count collective and EVERY rank, the failing
+ * one included, returns AGZ_RCCL_ERROR (its message names the rank; the failing rank's also carries its own
+ * reason) -- nobody is left waiting in ncclAllGather. */
 agz_status agz_allgather_records(agz_engine* e, agz_comm* comm, int64_t* added_out);
 /* The host logic between the two collectives of that exchange, for a host that carries the bytes with its own
  * library (MPI.jl, Distributed, torch.distributed/gloo) and finishes with agz_replay_ingest_gathered:

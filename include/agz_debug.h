@@ -27,9 +27,17 @@ int32_t agz_debug_counters(agz_engine* e, uint64_t* out, int32_t cap);
 /* Bench / soak-test population shaping, never part of the reference's behaviour: every game started from now on (also
  * the recycled ones) begins with a random legal opening prefix of up to `moves` plies and its first search gets a
  * random fraction of the readout budget, so that concurrent games sit at mixed stages and phases from the first timed
- * step (that first, shortened move is not counted as a position).  0 = off (the default).  Call it before
- * agz_selfplay_start; not available in arena_mode. */
+ * step (that first, shortened move is not counted as a position).  0 = off (the default).  Call it before the first
+ * step of a run (AGZ_BAD_ARGUMENT once agz_selfplay_step has run since the last agz_selfplay_start); not available
+ * in arena_mode. */
 agz_status agz_debug_set_stagger(agz_engine* e, int32_t moves);
+
+/* The record of a game that is still being played: slot g's game id and the moves it has recorded so far (return value
+ * through *num_moves_out), and -- for 0 <= k < that -- move k, its pi[A] and q (any of the three may be NULL; k < 0 reads
+ * only the header).  Lets a parity test hold the first moves of full-size runs against the oracle without waiting for
+ * the games to end (tests/test_gpu_selfplay.py).  Synchronises. */
+agz_status agz_debug_live_record(agz_engine* e, int32_t g, int32_t k, uint64_t* game_id_out, int32_t* num_moves_out,
+                                 int32_t* move_out, float* pi_out, float* q_out);
 
 /* Measurement context for bench.py's roofline object: the f32 MFMA rate (TFLOP/s) this board SUSTAINS on nothing but
  * independent v_mfma_f32_32x32x2_f32 from registers -- back-to-back ~10 ms launches for `millis` (50..5000), median of the

@@ -139,7 +139,7 @@ def test_two_rank_gloo_weight_broadcast():
 
 # ---- Engine.allgather_records_hosted (the host-carried exchange) over a stub of the C ABI --------------------------------
 class StubAbi:
-    """The five entry points Engine.allgather_records_hosted calls, over numpy: `records` is this rank's packed export.
+    """The entry points Engine.allgather_records_hosted calls, over numpy: `records` is this rank's packed export.
     agz_gather_plan is the REAL library's (pure host code); everything else is a stand-in for an engine on a GPU."""
 
     def __init__(self, packed, nrec, fail_status=0):
@@ -156,6 +156,9 @@ class StubAbi:
 
     def agz_records_count(self, h):
         return self.nrec
+
+    def agz_engine_sync(self, h):          # (the real method orders the engine's stream against torch's around the pack)
+        return 0
 
     def agz_gather_plan(self, *a):
         return self.real.agz_gather_plan(*a)

@@ -140,6 +140,20 @@ def test_three_ranks_one_of_them_with_nothing_to_send():
     assert all(got[r]["added"] == 6 for r in range(3))
 
 
+def test_eight_ranks_with_sixteen_or_more_games_each():
+    """BASELINE configs[2]'s world size (8 ranks; here all on one GPU) with unequal, non-trivial loads -- 16 to 23 finished
+    games per rank and one rank with none: every arena is the same 129 games in rank order (VERDICT r3 #6)"""
+    per_rank = [17, 16, 20, 0, 19, 16, 23, 18]
+    got = run_world(per_rank)
+    arenas = [got[r]["arena"] for r in range(8)]
+    assert all(a == arenas[0] for a in arenas) and len(arenas[0]) == sum(per_rank)
+    assert [d[0] % 8 for d in arenas[0]] == [r for r, n in enumerate(per_rank) for _ in range(n)]
+    assert all(got[r]["added"] == sum(per_rank) and got[r]["positions"] == got[0]["positions"] for r in range(8))
+    for r in range(8):
+        assert sorted(d for d in arenas[0] if d[0] % 8 == r) == sorted(got[r]["own"])
+        assert got[r]["again"] == 0 and got[r]["count_after"] == sum(per_rank)
+
+
 def test_a_rank_failing_before_the_exchange_fails_every_rank():
     got = run_world([2, 2], fail_rank=1)
     import alphago_jl_amd as ag
@@ -164,4 +178,23 @@ def test_bench_two_ranks_single_device_runs_the_whole_exchange_leg():
     ex = d["exchange"]
     assert "error" not in ex, ex
     assert ex["consistent"] and ex["games_in_arena"] == sum(ex["own_games_by_rank"]) > 0
-    assert all(n > 0 for n in ex["own_games_by_rank"]) and ex["positions_in_arena"] > 0
+    assert min(ex["own_games_by_rank"]) >= 16 and ex["positions_in_arena"] > 0
+
+
+def test_bench_eight_ranks_single_device_exchanges_sixteen_games_per_rank():
+    """the same leg at BASELINE configs[2]'s world size: 8 ranks under torch.distributed.run (all on cuda:0), every rank
+    with >= 16 finished games before the exchange"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--single-device-test",
+           "--board", "5", "--tower", "1", "--readouts", "16", "--games", "32", "--steps", "30", "--warmup", "2",
+           "--stagger", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    ex = d["exchange"]
+    assert "error" not in ex, ex
+    assert ex["consistent"] and ex["games_in_arena"] == sum(ex["own_games_by_rank"])
+    assert len(ex["own_games_by_rank"]) == 8 and min(ex["own_games_by_rank"]) >= 16, ex

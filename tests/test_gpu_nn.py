@@ -70,12 +70,15 @@ def test_forward_matches_oracle(N, tower, B, winograd):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32s"])
-@pytest.mark.parametrize("N", [3, 4, 6, 8, 10, 12, 13, 16])
+@pytest.mark.parametrize("N", [3, 4, 6, 8, 10, 12, 13, 16, 19])
 def test_every_tiling_class_of_the_winograd_tower(N, precision):
     """Tile blocks hold whole boards for N <= 12 (T*T = 1, 4, 9, 16 tiles per board: 64, 64, 63, 64 rows used,
     next layer's input transform fused into the GEMM epilogue) and are packed densely above (N = 13..15: 25
-    tiles, 16..18: 36, 19: 49; separate input transform); boards whose side is not a multiple of 3 have tiles
-    hanging over the edge.  One parity check per class, batch sizes that leave a partial last block."""
+    tiles, 16..18: 36, 19: 49 -- or fewer, larger tiles where F(4x4,3x3) takes over; the epilogue emits the V of every
+    tile whose input patch lies inside its block and a fix-up transform does the block ends); boards whose side is not
+    a multiple of the tile have tiles hanging over the edge.  One parity check per class, batch sizes that leave a
+    partial last block; a position's output must not depend on its batch row (which decides, for dense blocks, which
+    of the two producers of V a tile gets)."""
     tower, B = 2, 23
     A = N * N + 1
     rng = np.random.RandomState(N)
@@ -92,6 +95,9 @@ def test_every_tiling_class_of_the_winograd_tower(N, precision):
     assert np.abs(gpi - pi64).max() <= TOL and np.abs(gv - v64).max() <= TOL, (np.abs(gpi - pi64).max(), np.abs(gv - v64).max())
     spi, sv = eng.forward_features(feats[5:6])
     assert (spi[0] == gpi[5]).all() and sv[0] == gv[5]
+    for lo in (1, 2, 7, 11):                        # the same positions at other block rows
+        spi, sv = eng.forward_features(feats[lo:])
+        assert (spi == gpi[lo:]).all() and (sv == gv[lo:]).all(), lo
     L.or_net_free(onet)
     eng.close()
 
@@ -122,11 +128,17 @@ def test_weight_shape_errors():
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16", "f32s"])
-def test_full_batch_is_deterministic_and_matches_small_batches(precision):
-    """race screen at the bench's batch size (8192 positions, every CU busy, DMA rings full): repeated
-    forwards are bit-identical, and so is a slice evaluated as a small batch"""
-    N, tower, B = 9, 4, 8192
+@pytest.mark.parametrize("N,tower,B,precision", [
+    (9, 4, 8192, "f32"), (9, 4, 8192, "f16"), (9, 4, 8192, "f32s"),      # the bench's batch (configs[1])
+    (19, 2, 2048, "f32"), (19, 2, 2048, "f32s"),                         # configs[3]'s shard: dense tile blocks
+    (19, 2, 4096, "f16"),                                                # configs[4]'s shard
+])
+def test_full_batch_is_deterministic_and_matches_small_batches(N, tower, B, precision):
+    """race screen at the full batch sizes (every CU busy, DMA rings full): repeated forwards are bit-identical, and so
+    is a slice evaluated as a small batch.  At 19x19 tile blocks are packed densely: a tile's V comes from the GEMM
+    epilogue of the layer before or from the fix-up transform depending on where its batch row puts it in a block, so
+    slices that start at different rows (every residue of the 49- / 25-tile board stride against the 64-row blocks)
+    check that the two producers agree to the bit (VERDICT r3 #3b)."""
     rng = np.random.RandomState(1)
     eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
     eng.init_synthetic(2)
@@ -134,11 +146,12 @@ def test_full_batch_is_deterministic_and_matches_small_batches(precision):
     feats = (rng.rand(B, 17 * N * N) < 0.25).astype(np.float32)
     feats[:, 16 * N * N:] = np.where(rng.rand(B, 1) < 0.5, 1.0, -1.0)
     pi0, v0 = eng.forward_features(feats)
-    for _ in range(6):
+    for _ in range(6 if N == 9 else 3):
         pi, v = eng.forward_features(feats)
         assert (pi == pi0).all() and (v == v0).all()
-    for lo in (0, 3000, B - 300):
-        spi, sv = eng.forward_features(feats[lo:lo + 300])
-        assert (spi == pi0[lo:lo + 300]).all() and (sv == v0[lo:lo + 300]).all(), lo
+    n = 300 if N == 9 else 67
+    for lo in (0, 3000 % (B - n), B - n, 1, 977 % (B - n)):
+        spi, sv = eng.forward_features(feats[lo:lo + n])
+        assert (spi == pi0[lo:lo + n]).all() and (sv == v0[lo:lo + n]).all(), lo
     assert np.isfinite(pi0).all() and np.allclose(pi0.sum(1), 1, atol=1e-5)
     eng.close()

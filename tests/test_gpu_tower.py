@@ -1,4 +1,4 @@
-"""The f32 Winograd tower as ONE persistent launch (k_wino_tower, the default where it applies) against the same tower
+"""The f32 Winograd tower as ONE persistent launch (k_wino_tower: opt-in, agz_net_set_tower_persistent) against the same tower
 as one launch per layer: the same device function runs each (layer, tile block, cout block) either way, so the
 network's outputs must agree BIT FOR BIT -- any difference is a scheduling / visibility bug of the persistent kernel
 (a tile block read before its producer's stores arrived), not rounding.  Repeated, on warm caches, at batch sizes
