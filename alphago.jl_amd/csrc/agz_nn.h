@@ -25,6 +25,8 @@ struct DenseHost {
   std::vector<float> w, b;
 };
 
+bool wino4_applies(int N);      // agz_wino4.hip (declared with the rest of its interface below)
+
 class Net {
  public:
   Net(int N, int tower, hipStream_t stream);
@@ -47,9 +49,11 @@ class Net {
   // one tower conv launch on resident synthetic activations (for roofline timing)
   void launch_tower_conv_once(const int* d_count, int bcap);
 
-  // tower convolution algorithm: Winograd F(3x3,3x3) (default) or the direct implicit GEMM
-  void set_winograd(bool on) { winograd_ = on; }
+  // tower convolution algorithm: 1 = Winograd (default: F(3x3,3x3), and F(4x4,3x3) for boards of 13x13 and larger in the
+  // exact-f32 arithmetic), 2 = Winograd F(3x3,3x3) on every board size (A/B runs), 0 = the direct implicit GEMM
+  void set_winograd(int mode) { winograd_ = mode != 0; wino_f33_only_ = mode == 2; }
   bool winograd() const { return winograd_; }
+  bool use_wino4() const { return winograd_ && !wino_f33_only_ && precision_ == 0 && tower_ > 0 && wino4_applies(N_); }
   // the f32 Winograd tower as ONE persistent launch (k_wino_tower) instead of one launch per layer, where it applies
   // (whole-board tile blocks, 256 CUs with 32 resident workgroups per XCD); same arithmetic, same bits.  Off by
   // default: it needs 3.7 % fewer cycles and the clock comes down by as much -- same wall time.
@@ -114,7 +118,9 @@ class Net {
   // workspace
   int bcap_ = 0;
   DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
-  bool winograd_ = true;
+  bool winograd_ = true, wino_f33_only_ = false;
+  DevBuf<float> d_uwino4_;                     // F(4x4,3x3) transformed weights (agz_wino4.hip), packed when first used
+  bool packed4_ = false;
   DevBuf<float> d_uwino_s_, d_scale_s_;        // split form: weights as halves, scale x 1 / (operand scales)
   bool packed_split_ = false;
   DevBuf<float> d_uwino_, d_vimg_, d_vimg2_;   // transformed weights (stage images) / transformed activations (ping-pong)
@@ -202,6 +208,20 @@ constexpr int kWinoTowerErrWord = 8;         // int offset of the scheduler's er
 // split-operand form (AGZ_PRECISION_F32S): weights as (hi, lo) halves of 2^10 u; 1 / (operand scales) for the epilogue
 void wino_pack_weights_split(const ConvHost& c, float* out, int ns = kWinoStages);
 float wino_split_descale();
+
+// Winograd F(4x4,3x3) tower convolution for boards of 13x13 and larger (agz_wino4.hip): 36 planes in four passes over
+// the input channels, each folded into the inverse transform when its K loop ends; tiles of 4x4 outputs, T = ceil(N / 4)
+constexpr int kWino4Stages = 96;             // K-loop stages of a layer: 32 + 32 (12 planes x 8 cin) + 16 + 16 (6 planes x 16 cin)
+bool wino4_applies(int N);                   // N >= 13: fewer multiplies per output point than F(3x3,3x3)
+bool wino4_whole_boards(int N);              // tile blocks hold whole boards (N = 13..16); else dense blocks + fix-up transform
+void wino4_pack_weights(const ConvHost& c, float* out);
+size_t wino4_weight_floats();
+size_t wino4_v_floats(int bcap, int N);
+// x -> V (all tiles), or with fixup only the tiles the previous GEMM's epilogue could not emit (dense blocks)
+void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s, bool fixup);
+// V, U -> y (if y != NULL) and / or the next layer's V (if vnext != NULL)
+void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
+                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s);
 
 // fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged
 void conv16_pack_images(const ConvHost& c, uint16_t* out);

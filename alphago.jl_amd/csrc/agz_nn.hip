@@ -503,6 +503,15 @@ void Net::pack() {
     AGZ_HIP(hipStreamSynchronize(stream_));
     packed_split_ = true;
   }
+  if (use_wino4() && (dirty_ || !packed4_)) {
+    const size_t per4 = wino4_weight_floats();
+    std::vector<float> u(per4 * 2 * tower_);
+    for (int l = 0; l < 2 * tower_; ++l) wino4_pack_weights(tconv_[l], u.data() + per4 * l);
+    d_uwino4_.ensure(u.size());
+    AGZ_HIP(hipMemcpyAsync(d_uwino4_.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    AGZ_HIP(hipStreamSynchronize(stream_));
+    packed4_ = true;
+  }
   if (!dirty_ && (precision_ != 1 || packed16_)) return;
   if (precision_ == 1 && tower_ > 0 && (dirty_ || !packed16_)) {
     const size_t iper = conv16_image_halves();
@@ -516,6 +525,7 @@ void Net::pack() {
   if (!dirty_) return;
   if (precision_ != 1) packed16_ = false;
   if (precision_ != 2) packed_split_ = false;
+  if (!use_wino4()) packed4_ = false;
   const int L = 1 + 2 * tower_;
   std::vector<float> scale((size_t)L * kC), shift((size_t)L * kC);
   {
@@ -588,8 +598,9 @@ void Net::reserve(int bcap) {
   d_vh_.alloc(rows);
   d_ph_.alloc(rows * 2);
   if (tower_ > 0) {
-    d_vimg_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
-    d_vimg2_.alloc(wino_v_floats(bcap, (N_ + 2) / 3));
+    const size_t vf = std::max(wino_v_floats(bcap, (N_ + 2) / 3), wino4_applies(N_) ? wino4_v_floats(bcap, N_) : (size_t)0);
+    d_vimg_.alloc(vf);
+    d_vimg2_.alloc(vf);
   }
   bcap_ = bcap;
 }
@@ -717,6 +728,33 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       // (round 2 ran the full k_wino_in in front of every layer there: 20 % of a step, MFMA pipe idle).
       const bool dense = !wino_fusable(N_);
       float *vcur = d_vimg_.p, *vnxt = d_vimg2_.p;
+      if (use_wino4() && stem_wino) {
+        // Boards of 13x13 and larger, exact f32: the tower on F(4x4,3x3) (agz_wino4.hip: 2.49 multiplies per output point
+        // at 19x19 against 3.39).  The stem stays an 8-stage F(3x3,3x3) GEMM (y only); one full input transform in front
+        // of the first tower layer, then every layer's epilogue emits the next V -- all of it when tile blocks hold
+        // whole boards (N = 13..16), the block ends through the fix-up transform otherwise.
+        const size_t per4 = wino4_weight_floats();
+        const bool dense4 = !wino4_whole_boards(N_);
+        launch_wino_in(d_x32, vnxt, d_count, bcap, N_, false, stream_, kWinoStemStages);
+        launch_wino_gemm(vnxt, d_ustem_.p, d_scale_.p, d_shift_.p, nullptr, a, nullptr, d_count, bcap, N_, 1, false, stream_,
+                         kWinoStemStages);
+        launch_wino4_in(a, vcur, d_count, bcap, N_, stream_, false);
+        for (int blk = 0; blk < tower_; ++blk) {
+          const int l1 = 2 * blk, l2 = 2 * blk + 1;
+          const bool last = blk + 1 == tower_;
+          timed([&] {
+            launch_wino4_gemm(vcur, d_uwino4_.p + per4 * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, dense4 ? t : nullptr,
+                              vnxt, d_count, bcap, N_, 1, stream_);
+            if (dense4) launch_wino4_in(t, vnxt, d_count, bcap, N_, stream_, true);
+          });
+          timed([&] {
+            launch_wino4_gemm(vnxt, d_uwino4_.p + per4 * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, a, b, last ? nullptr : vcur,
+                              d_count, bcap, N_, 1, stream_);
+            if (dense4 && !last) launch_wino4_in(b, vcur, d_count, bcap, N_, stream_, true);
+          });
+          std::swap(a, b);
+        }
+      } else {
       if (stem_wino) {
         launch_wino_in(d_x32, vnxt, d_count, bcap, N_, split, stream_, kWinoStemStages);
         launch_wino_gemm(vnxt, split ? d_ustem_s_.p : d_ustem_.p, split ? d_scale_s_.p + (size_t)2 * tower_ * kC : d_scale_.p,
@@ -773,6 +811,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
           if (dense && !last) launch_wino_in(b, vcur, d_count, bcap, N_, split, stream_, kWinoStages, true);
         });
         std::swap(a, b);
+      }
       }
     } else {                                         // the direct implicit GEMM (agz_net_set_winograd(0)); the stem ran above
       for (int blk = 0; blk < tower_; ++blk) {
@@ -891,6 +930,10 @@ void Net::launch_tower_conv_once(const int* d_count, int bcap) {
   if (precision_ == 1)
     launch_conv16_dma(d_ha_.p, d_wi16_.p, d_scale_.p + kC, d_shift_.p + kC, nullptr, 0, d_ht_.p, 0, d_count, bcap, N_, 1,
                       stream_);
+  else if (use_wino4()) {
+    launch_wino4_gemm(d_vimg_.p, d_uwino4_.p, d_scale_.p + kC, d_shift_.p + kC, d_a_.p, d_t_.p, d_vimg2_.p, d_count, bcap, N_, 1, stream_);
+    if (!wino4_whole_boards(N_)) launch_wino4_in(d_t_.p, d_vimg2_.p, d_count, bcap, N_, stream_, true);
+  }
   else if (winograd_ && wino_fusable(N_)) {   // a steady-state tower layer: residual in, y and the next V out
     const bool split = precision_ == 2;
     launch_wino_gemm(d_vimg_.p, split ? d_uwino_s_.p : d_uwino_.p, split ? d_scale_s_.p : d_scale_.p + kC, d_shift_.p + kC,

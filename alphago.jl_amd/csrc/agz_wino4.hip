@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
     float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
   __shared__ __attribute__((aligned(256))) float lds[3 * W4STAGE];      // 144 KB: stage buffers, then the half image
   __shared__ int ptab[W4T * 16];            // element offset of output point X = k * 64 + row in y / res, or -1
-  __shared__ __attribute__((aligned(16))) float zeros[4];
+  __shared__ __attribute__((aligned(256))) float zeros[64];      // what phase 2 reads for a patch point off the board
   const int P = N * N, TT = T * T;
   const int RPB = w4_rows_per_block(T);
   const long Mt = (long)(*d_count) * TT;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
 #pragma unroll
   for (int j = 0; j < 12; ++j) dma(0, 0, j);
 
-  if (tid < 4) zeros[tid] = 0.f;
+  if (tid < 64) zeros[tid] = 0.f;
   for (int idx = tid; idx < W4T * 16; idx += 256) {     // (published by the barrier in front of the first operand reads)
     const int row = idx & (W4T - 1), k = idx >> 6;
     const long tile = (long)tb * RPB + row;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   // lanes of a ds_read_b128 group (consecutive rows) then cover 64 banks once, and an LDS-DMA instruction fills eight
   // rows (1 KB), each lane choosing the global 16 B that belong in its slot.
   float* img = lds;
-  typedef __attribute__((address_space(3))) float lds_f;
+  
   const int trow = wm * 32 + l31;                       // this lane's tile row
   float sc[16], sh[16];
 #pragma unroll
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                       // every wave has left the K loop: the stage buffers are dead
 
-#pragma unroll 1
-  for (int hh = 0; hh < 2; ++hh) {
+  auto half = [&](auto hh_c) {
+    constexpr int hh = decltype(hh_c)::value;
     if (res) {
       // instruction n of wave w fills image rows 8 (w + 4 n) .. + 7: lane = (row X, slot s) fetches unit s ^ ((X >> 1) & 7)
 #pragma unroll 4
@@ -444,25 +444,11 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
         const unsigned boff = off >= 0 ? 4u * (unsigned)(off + hh * W4CP + 4 * u) : 0u;
         glds16s(res, boff, lds0 + (unsigned)(i * 256) * 4u);
       }
-    }
-    // the value, in registers: the lane's two register quads of this half for each of the 16 output points
-    f32x4 val[16][2];
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-#pragma unroll
-      for (int qd = 0; qd < 2; ++qd)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          // (compile-time register index in either half: the two halves are two copies of this code selected by hh)
-          const float y0 = Y[k][4 * qd + c], y1 = Y[k][8 + 4 * qd + c];
-          const float s0 = sc[4 * qd + c], s1 = sc[8 + 4 * qd + c], h0 = sh[4 * qd + c], h1 = sh[8 + 4 * qd + c];
-          val[k][qd][c] = hh ? __builtin_fmaf(y1, s1, h1) : __builtin_fmaf(y0, s0, h0);
-        }
-    if (res) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual half-tile has landed, for every wave
       __syncthreads();
     }
-    // img = ReLU(img (the residual) + value): unit wn * 4 + 2 qd + hi of row X = k * 64 + trow
+    // img = ReLU(img (the residual) + scale * value + shift): the lane's two register quads of this half for each of the
+    // 16 output points; unit wn * 4 + 2 qd + hi of row X = k * 64 + trow
     {
       const unsigned rowb = lds0 + 4u * (unsigned)(trow * W4CP);
       const int swz = (trow >> 1) & 7;                   // (X >> 1) & 7 = (trow >> 1) & 7: k * 64 does not reach bits 1..3
@@ -481,9 +467,13 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
           const unsigned kb = 4u * (unsigned)((k0 + kk) * W4T * W4CP);
 #pragma unroll
           for (int qd = 0; qd < 2; ++qd) {
-            f32x4 v = val[k0 + kk][qd] + rr[kk][qd];
+            f32x4 v;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], relu_lo);
+            for (int c = 0; c < 4; ++c) {
+              constexpr int e0 = 8 * hh;
+              const int e = e0 + 4 * qd + c;
+              v[c] = fmaxf(__builtin_fmaf(Y[k0 + kk][e], sc[e], sh[e]) + rr[kk][qd][c], relu_lo);
+            }
             *(__attribute__((address_space(3))) f32x4*)(size_t)((qd ? a1 : a0) + kb) = v;
           }
         }
@@ -523,9 +513,9 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
       const bool emit = w4_whole_boards(T) || (live && w4_tile_fused(T, row, ti, tj));
       // Patch point (u, v) of tile (ti, tj) is board point (4 ti - 1 + u, 4 tj - 1 + v): output (ku, kv) of the tile du
       // tile rows / dv tiles further on, (du, ku) = (-1, 3), (0, 0..3), (1, 0) for u = 0..5.  A point off the board (or a
-      // lane that emits nothing) reads 16 bytes of zeros instead of being masked out.  adr[q]: LDS byte address of the
+      // lane that emits nothing) reads a block of zeros instead of being masked out.  adr[q]: LDS byte address of the
       // point's unit for group `wave` (+ the lane's pair order: rows with bit 4 set store pair 1 first, so they read it
-      // first); group wave + 4 is the same address with bit 6 flipped (slot ^ 4).
+      // first); group wave + 4 is the same address with bit 6 flipped (slot ^ 4) -- also inside the 256-byte zeros block.
       unsigned adr[36];
       const unsigned zadr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&zeros[0];
 #pragma unroll
@@ -542,17 +532,15 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
 #pragma unroll 1
       for (int it = 0; it < 2; ++it) {
         const int g = wave + 4 * it;
+        const unsigned xo = (unsigned)it << 6;
         f32x4 d[36];
 #pragma unroll
         for (int q = 0; q < 36; ++q) {
-          // the zeros block is 16 bytes: its two halves are addressed without the slot flip
-          const unsigned a0 = adr[q] == zadr ? zadr : (adr[q] ^ ((unsigned)it << 6));
+          const unsigned a0 = adr[q] ^ xo;
           const f32x2 a = *(const __attribute__((address_space(3))) f32x2*)(size_t)a0;
           const f32x2 b = *(const __attribute__((address_space(3))) f32x2*)(size_t)(a0 ^ 8u);
           d[q] = (f32x4){a[0], a[1], b[0], b[1]};
         }
-        int stg[2][2];      // [rows 1..4 | rows 0, 5] -> nothing to precompute per plane: w4_slot is compile-time per (i, j)
-        (void)stg;
         const int c = cb * 16 + hh * 8 + g;               // the next layer's channel group
         float* gbase = vnext + (long)tb * W4BLOCK + row * 4;
         f32x2 vv[36][2];
@@ -576,24 +564,27 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
             for (int j = 0; j < 6; ++j) vv[i * 6 + j][hp] = r[j];
           }
         }
+        // (the channel group's stage / unit bases: rows 1..4 live in stages c >> 1 (+ 32), rows 0 and 5 in 64 / 80 + (c >> 2))
+        const int base12 = (c >> 1) * W4HALF + (c & 1) * 12 * W4UNIT, base6 = (c >> 2) * W4HALF + (c & 3) * 6 * W4UNIT;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            int stage_, unit_;
-            w4_slot(i, j, c, stage_, unit_);
+            const int o = (i == 1 || i == 2) ? base12 + ((i - 1) * 6 + j) * W4UNIT
+                        : (i == 3 || i == 4) ? 32 * W4HALF + base12 + ((i - 3) * 6 + j) * W4UNIT
+                        : i == 0 ? 64 * W4HALF + base6 + j * W4UNIT : 80 * W4HALF + base6 + j * W4UNIT;
             const f32x2 p0 = vv[i * 6 + j][0], p1 = vv[i * 6 + j][1];
             const f32x4 v4 = {p0[0], p0[1], p1[0], p1[1]};      // (already in the row's pair order: see the reads above)
-            f32x4* gp = reinterpret_cast<f32x4*>(gbase + (long)stage_ * W4HALF + unit_ * W4UNIT);
+            f32x4* gp = reinterpret_cast<f32x4*>(gbase + o);
             if (emit) __builtin_nontemporal_store(v4, gp);
           }
       }
     }
-    if (hh == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stores and loads share vmcnt: nothing of this half is counted into the next half's residual wait)
-      __syncthreads();                                   // every wave has left the image: the second half may overwrite it
-    }
-  }
+  };
+  half(std::integral_constant<int, 0>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stores and loads share vmcnt: nothing of the first half is counted into the second half's residual wait)
+  __syncthreads();                                   // every wave has left the image: the second half may overwrite it
+  half(std::integral_constant<int, 1>{});
 }
 
 // ------------------------------------------------------------------ host side

@@ -235,6 +235,9 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32s"],
                     help="tower arithmetic: f32 (default, the BASELINE metric), f16 = the fp16 MFMA path of BASELINE configs[4], "
                          "f32s = the f32 network with Winograd operands split into two f16 halves (fp16 MFMA, f32-grade results)")
+    ap.add_argument("--winograd", type=int, default=1, choices=[0, 1, 2],
+                    help="agz_net_set_winograd: 1 = default (F(4x4,3x3) from 13x13 up in exact f32, else F(3x3,3x3)), "
+                         "2 = F(3x3,3x3) everywhere, 0 = direct implicit GEMM")
     ap.add_argument("--tower-persistent", action="store_true",
                     help="run the f32 Winograd tower as one persistent launch (agz_net_set_tower_persistent; same bits, DESIGN.md 4f)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the 0.4 s sustained-MFMA-rate measurement behind the timed region")
@@ -287,6 +290,8 @@ def main():
                     stagger_moves=args.stagger)
     eng.init_synthetic(0)
     eng.set_precision(args.precision)
+    if args.winograd != 1:
+        eng.set_winograd(args.winograd)
     if args.tower_persistent:
         eng.set_tower_persistent(True)
     eng.start(0)
@@ -478,7 +483,11 @@ def main():
         fpos = R * f_eval(N, tower)
         T = (N + 2) // 3
         f16, f32s = args.precision == "f16", args.precision == "f32s"
-        wino_ratio = 1.0 if f16 else 25.0 * T * T / (9.0 * N * N)   # executed / algorithmic multiplies of F(3x3,3x3)
+        # executed / algorithmic multiplies: F(3x3,3x3) needs 25 per 3x3 tile; boards of 13x13 and larger run the exact-f32
+        # tower on F(4x4,3x3) (agz_wino4.hip): 36 per 4x4 tile
+        f43 = (not f16) and (not f32s) and N >= 13 and args.winograd == 1
+        T4 = (N + 3) // 4
+        wino_ratio = 1.0 if f16 else (36.0 * T4 * T4 / (9.0 * N * N) if f43 else 25.0 * T * T / (9.0 * N * N))
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), N, args.precision)
         # The roofline object.  `achieved`/`frac` are what the MFMA pipe EXECUTES: Winograd F(3x3,3x3) needs 25
@@ -505,7 +514,8 @@ def main():
         roofline = roofline if f32s else {
             "bound": "mfma",
             "kernel": "3x3 256->256 tower conv = k_conv3x3_f16 (implicit GEMM, v_mfma_f32_32x32x16_f16)" if f16 else
-                      "3x3 256->256 tower conv (Winograd F(3x3,3x3) on v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)",
+                      ("3x3 256->256 tower conv (Winograd F(4x4,3x3) in four passes on v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)" if f43 else
+                       "3x3 256->256 tower conv (Winograd F(3x3,3x3) on v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)"),
             "achieved": exe_tf, "peak": peak, "unit": "TFLOP/s",
             "frac": exe_tf / peak if exe_tf is not None else None,
             "achieved_algorithmic": alg_tf,
