@@ -71,12 +71,10 @@ constexpr int W4CP = 32;                      // couts per epilogue half
 constexpr int W4IMG = 16 * W4T * W4CP;        // floats of the half image: 128 KB
 static_assert(W4NST == 96 && kC == 256, "pass structure below assumes 64 channel groups");
 
-// where plane (i, j) of 4-channel group c (0..63) lives: stage of the flat list, unit within the stage
+// where plane (i, j) of 4-channel group c (0..63) lives: pass = transform row i, 16 stages of 4 channel groups x 6 planes
 __host__ __device__ __forceinline__ void w4_slot(int i, int j, int c, int& stage, int& unit) {
-  if (i == 1 || i == 2) { stage = c >> 1; unit = (c & 1) * 12 + (i - 1) * 6 + j; }
-  else if (i == 3 || i == 4) { stage = 32 + (c >> 1); unit = (c & 1) * 12 + (i - 3) * 6 + j; }
-  else if (i == 0) { stage = 64 + (c >> 2); unit = (c & 3) * 6 + j; }
-  else { stage = 80 + (c >> 2); unit = (c & 3) * 6 + j; }
+  stage = i * 16 + (c >> 2);
+  unit = (c & 3) * 6 + j;
 }
 // a unit image row (either operand) is the unit's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1: rows r and
 // r + 16 start on the same bank and take different slots, so the 32-row ds_read_b64 of the K loop is conflict-free, and a
@@ -125,25 +123,32 @@ __device__ __forceinline__ void bt6(V x0, V x1, V x2, V x3, V x4, V x5, V* r) {
 }
 
 // ------------------------------------------------------------------ input transform (first layer; block ends)
-// x[M][256] -> V stage images.  grid = 2 x tile blocks (32-tile halves); 256 threads = 32 tiles x 8 lanes (a lane = one
-// channel pair of one of 4 channel groups): the eight lanes of a tile read one 64-byte run of every patch point.  A pass
-// covers 16 channels; the 36 transformed planes go to an LDS copy of this half-block's part of their unit images and leave
-// for HBM as whole 512-byte runs, 16 B per lane.  FIXUP (dense tile blocks only): only the tiles the previous layer's GEMM
-// epilogue could not emit (!w4_tile_fused) and the rows past the batch (zeros) are transformed and stored.
+// x[M][256] -> V stage images.  Full form: grid = 2 x tile blocks (32-tile halves); 256 threads = 32 tiles x 8 lanes (a
+// lane = one channel pair of one of 4 channel groups): the eight lanes of a tile read one 64-byte run of every patch
+// point.  A pass covers 16 channels; the 36 transformed planes go to an LDS copy of this half-block's part of their unit
+// images and leave for HBM as whole 512-byte runs, 16 B per lane.
+// FIXUP (dense tile blocks only): only the tiles the previous layer's GEMM epilogue could not emit (!w4_tile_fused).
+// Those are at most T + 1 <= 8 rows at either end of a block, so the grid is again 2 x tile blocks, but a workgroup
+// takes EIGHT rows (0..7 or 56..63) x 32 lanes (16 channel groups): 4 passes of 64 channels instead of 16 of 16 over
+// 32 mostly idle tiles (the first form of this kernel: 0.30 ms per layer, a tenth of it); rows in place are not touched.
 template <bool FIXUP>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T) {
-  constexpr int TPB = 32, CH = TPB * 4;          // floats per chunk: 32 rows of one unit
-  constexpr int IMG = 36 * CH + 8;               // stride between the four groups' copies (+8: bank skew of the 8-byte writes)
-  __shared__ __attribute__((aligned(16))) float img[4 * IMG];
+  constexpr int TPB = FIXUP ? 8 : 32;            // tile rows per workgroup
+  constexpr int LPT = 256 / TPB;                 // lanes per tile: 8 / 32
+  constexpr int GP = LPT / 2;                    // channel groups per pass: 4 / 16
+  constexpr int CH = TPB * 4;                    // floats per chunk: this workgroup's rows of one unit
+  constexpr int IMG = 36 * CH + 8;               // stride between the groups' copies (+8: bank skew of the 8-byte writes)
+  __shared__ __attribute__((aligned(16))) float img[GP * IMG];
   const int P = N * N, TT = T * T;
   const int RPB = w4_rows_per_block(T);
   const long Mt = (long)(*d_count) * TT;
   const int tb = blockIdx.x >> 1, part = blockIdx.x & 1;
-  if ((long)tb * RPB + part * TPB >= Mt) return;
-  const int hs = threadIdx.x & 7, h = hs & 1, sl = hs >> 1;
-  const int tl = threadIdx.x >> 3;
-  const int row = part * TPB + tl;
+  const int row0 = FIXUP ? part * (W4T - TPB) : part * TPB;      // first row of this workgroup
+  if ((long)tb * RPB + row0 >= Mt) return;
+  const int hs = threadIdx.x % LPT, h = hs & 1, sl = hs >> 1;
+  const int tl = threadIdx.x / LPT;
+  const int row = row0 + tl;
   const long tile = (long)tb * RPB + row;
   bool live = row < RPB && tile < Mt;
   const int b = live ? (int)(tile / TT) : 0, t = live ? (int)(tile % TT) : 0;
@@ -159,17 +164,18 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
       off[u * 6 + v] = ok ? (b * P + pi + N * pj) * kC : -1;               // < 2^31 (checked by the launcher)
     }
   float* mine = img + sl * IMG + tl * 4 + 2 * ((h + (row >> 4)) & 1);
-  float* gdst = vimg + (long)tb * W4BLOCK + part * CH;
-  const int cq = threadIdx.x >> 5, cl = threadIdx.x & 31;                 // copy-out: 8 chunks per round, 32 lanes each
+  float* gdst = vimg + (long)tb * W4BLOCK + row0 * 4;
+  constexpr int CPR = 256 / TPB;                                           // chunks copied out per round
+  const int cq = threadIdx.x / TPB, cl = threadIdx.x % TPB;
   bool copy_row = true;
-  if (FIXUP) {
-    const int crow = part * TPB + cl;
+  if (FIXUP) {      // only the rows this kernel computed leave (a dead row inside the range is written as zeros)
+    const int crow = row0 + cl;
     const long ctile = (long)tb * RPB + crow;
     const int ct = (int)(ctile % TT);
     copy_row = !(crow < RPB && ctile < Mt && w4_tile_fused(T, crow, ct / T, ct % T));
   }
-  for (int pass = 0; pass < kC / 16; ++pass) {
-    const int ch = pass * 16 + sl * 4 + 2 * h;
+  for (int pass = 0; pass < (kC / 4) / GP; ++pass) {
+    const int ch = (pass * GP + sl) * 4 + 2 * h;
     f32x2 d[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q)
@@ -191,12 +197,13 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
       for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(mine + (i * 6 + j) * CH) = r[j];
     }
     __syncthreads();
+    static_assert((GP * 36) % CPR == 0, "whole copy-out rounds");
 #pragma unroll
-    for (int r = 0; r < 18; ++r) {
-      const int c = r * 8 + cq, s4 = c / 36, pl = c - s4 * 36;            // chunk c = (group s4 of this pass, plane pl)
+    for (int r = 0; r < GP * 36 / CPR; ++r) {
+      const int c = r * CPR + cq, s4 = c / 36, pl = c - s4 * 36;          // chunk c = (group s4 of this pass, plane pl)
       const f32x4 v = *reinterpret_cast<const f32x4*>(img + s4 * IMG + pl * CH + cl * 4);
       int stage, unit;
-      w4_slot(pl / 6, pl % 6, pass * 4 + s4, stage, unit);
+      w4_slot(pl / 6, pl % 6, pass * GP + s4, stage, unit);
       f32x4* gp = reinterpret_cast<f32x4*>(gdst + (long)stage * W4HALF + unit * W4UNIT + cl * 4);
       if (FIXUP && !copy_row) continue;
       __builtin_nontemporal_store(v, gp);
@@ -206,19 +213,40 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
 
 // ------------------------------------------------------------------ GEMM in four passes + output transform + next input transform
 
-// A^T m for one transform row: six planes -> four tuples
-__device__ __forceinline__ void w4_fold_row(const f32x16& m0, const f32x16& m1, const f32x16& m2, const f32x16& m3,
-                                            const f32x16& m4, const f32x16& m5, f32x16* t) {
-  const f32x16 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+// A^T m for one transform row: six planes -> four values, on register PAIRS (elements 2 q, 2 q + 1 of the accumulator
+// tuples).  The running outputs are 128 independent pairs, not sixteen 16-register tuples: tuples need 16 consecutive
+// registers each, the file fragments, and hipcc parks whole tuples in scratch -- whose reloads wait, through vmcnt(0),
+// for every LDS-DMA piece in flight (the first form of the folds: 0.7 ms per layer, 60 cycles per instruction).
+__device__ __forceinline__ void w4_fold_row(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4,
+                                            const f32x2 m5, f32x2* t) {
+  const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
   t[0] = (m0 + s12) + s34;
   t[1] = d12 + 2.f * d34;
   t[2] = s12 + 4.f * s34;
   t[3] = (d12 + 8.f * d34) + m5;
 }
 
-// MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
+#ifdef AGZ_TIMING_EXPERIMENTS
+// per workgroup, on the 100 MHz wall clock: [0] hw id | xcc id << 32, [1] start, [2] prologue done (first stage published),
+// [3..8] end of pass 0..5 (K loop + fold), [9 + 4 hh + {0, 1, 2, 3}] half hh: residual landed, image written, y stored,
+// next V stored; tools/trace_wino4.py reads it
+__device__ unsigned long long w4_trace[8192][20];
+#define W4_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) w4_trace[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define W4_STAMP(k) do { } while (0)
+#endif
+
+// MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images; bit 2: add the residual.
 // X (timing experiments, -DAGZ_TIMING_EXPERIMENTS only; results WRONG): 1 = K loops and folds only; 2 = no phase 2;
-// 4 = no DMA after the prologue; 5 = no MFMA
+// 3 = phase 2 without its global stores; 4 = no DMA after the prologue; 5 = no MFMA; 6 = no folds; 7 = no LDS operand reads; 8 = neither DMA nor operand reads in the K loop; 9 = 8 without the stage barrier
+//
+// Code size is a design constraint here: the first form of this kernel (each pass's first stage and the two tail stages
+// peeled, the epilogue's halves as two copies: 65 KB of code) ran its straight-line sections -- folds, epilogue -- at
+// ~35 cycles per instruction, the K-loop bodies (1.7 KB each, resident) at full speed: the instruction cache (64 KB per CU
+// pair) does not hold a kernel of that size between a workgroup's visits.  So: every stage of a pass is the same loop
+// body (accumulators zeroed in front of a pass, the DMA of the last two stages wraps around to stages 0 and 1 and is
+// thrown away), passes C and D are one loop, and the epilogue's second half runs the first half's code after moving the
+// upper register quads down.
 template <int MODE, int X>
 __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
@@ -227,6 +255,7 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   __shared__ __attribute__((aligned(256))) float lds[3 * W4STAGE];      // 144 KB: stage buffers, then the half image
   __shared__ int ptab[W4T * 16];            // element offset of output point X = k * 64 + row in y / res, or -1
   __shared__ __attribute__((aligned(256))) float zeros[64];      // what phase 2 reads for a patch point off the board
+  constexpr bool RES = (MODE & 4) != 0;
   const int P = N * N, TT = T * T;
   const int RPB = w4_rows_per_block(T);
   const long Mt = (long)(*d_count) * TT;
@@ -243,16 +272,25 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
 
+#ifdef AGZ_TIMING_EXPERIMENTS
+  if (tid == 0 && blockIdx.x < 8192) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    w4_trace[blockIdx.x][0] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
+  W4_STAMP(1);
+#endif
   const float* asrc = vimg + (long)tb * W4BLOCK;
   const float* bsrc = uimg + (long)cb * W4BLOCK;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0];
 
   // a stage is 48 pieces of 1 KB: 0..23 V units, 24..47 U units; wave w moves pieces 12 w .. 12 w + 11 (waves 0, 1: V;
   // 2, 3: U), wave-uniform base in SGPRs + a 32-bit lane offset
+  const float* wsrc = (wave < 2 ? asrc : bsrc - 24 * W4UNIT) + 12 * wave * W4UNIT;
   auto dma = [&](int st, int buf, int j) {
     const int c = 12 * wave + j;
-    const float* g = wave < 2 ? asrc + (long)st * W4HALF + c * W4UNIT : bsrc + (long)st * W4HALF + (c - 24) * W4UNIT;
-    glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * W4STAGE + c * W4UNIT) * 4u);
+    glds16s(wsrc + (long)st * W4HALF + j * W4UNIT, (unsigned)lane * 16u, lds0 + (unsigned)(buf * W4STAGE + c * W4UNIT) * 4u);
   };
 #pragma unroll
   for (int j = 0; j < 12; ++j) dma(0, 0, j);
@@ -273,10 +311,14 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
 #pragma unroll
   for (int j = 0; j < 12; ++j) dma(1, 1, j);
 
-  f32x16 acc[12];
+  f32x16 acc[6];
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
   const int aoff = w4_off(arow, hi), boff = W4HALF + w4_off(brow, hi);
-  constexpr int LA = 5, RING = LA + 1;       // 24 % RING == 0: ring slots are compile-time within a stage
+#ifndef W4_LA
+#define W4_LA 5
+#endif
+  constexpr int LA = W4_LA, RING = LA + 1;       // 24 % RING == 0: ring slots are compile-time within a stage
+  static_assert(W4UNITS % RING == 0, "ring slots must be compile-time within a stage");
   float2 ra[RING], rb[RING];
   auto load = [&](const float* L, int u, float2& a, float2& b) {
     a = *reinterpret_cast<const float2*>(L + aoff + u * W4UNIT);
@@ -284,10 +326,6 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   };
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // transposed: srcA = U (its rows become D's rows = registers: couts), srcB = V (D's columns = lanes: tile rows)
-  auto mma0 = [&](int p, const float2& a, const float2& b) {
-    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, zero16, 0, 0, 0);
-    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[p], 0, 0, 0);
-  };
   auto mma = [&](int p, const float2& a, const float2& b) {
     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[p], 0, 0, 0);
     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[p], 0, 0, 0);
@@ -295,172 +333,177 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
 
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 has landed (stage 1's 12 pieces may be in flight)
   __syncthreads();
+  W4_STAMP(2);
+#pragma unroll
+  for (int u = 0; u < RING; ++u) ra[u] = rb[u] = make_float2(1.f, 0.5f);
 #pragma unroll
   for (int u = 0; u < LA; ++u) load(lds, u, ra[u], rb[u]);
 
-  // One stage of a pass with PL planes (unit u = group * PL + plane).  MORE: stage st + 2 exists and is fetched during
-  // this stage; NEXT: stage st + 1 exists; FIRST: the pass's first stage (its planes' first MFMAs take C = 0).
+  // One stage: 24 units = 4 channel groups x the pass's 6 planes (unit u = group * 6 + plane).  Every stage fetches stage
+  // st + 2 (the last two wrap around to stages 0 and 1: valid memory, never read) and hands over to stage st + 1 through
+  // the barrier in its read stream -- one loop body for the whole kernel.
   int buf = 0;
-  auto stage = [&](int st, auto pl_c, auto more_c, auto next_c, auto first_c) {
-    constexpr int PL = decltype(pl_c)::value;
-    constexpr bool more = decltype(more_c)::value, next = decltype(next_c)::value, first = decltype(first_c)::value;
+  auto stage = [&](int st) {
+    constexpr int PL = 6;
     const int nbuf = buf == 2 ? 0 : buf + 1;
     const int dbuf = buf == 0 ? 2 : buf - 1;
+    const int st2 = st + 2 >= W4NST ? st + 2 - W4NST : st + 2;
     const float* L = lds + buf * W4STAGE;
     const float* Ln = lds + nbuf * W4STAGE;
 #pragma unroll
     for (int u = 0; u < W4UNITS; ++u) {
       const int t = u + LA;
-      if (t == W4UNITS && next) {
+      if (t == W4UNITS) {
         // everything this wave owes to stage st + 1 has landed (its 12 pieces of stage st + 2, all issued by now, may be
         // in flight); hipcc adds lgkmcnt(0) in front of the barrier: all reads of stage st are back
-        if (more && X != 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (X != 4 && X != 8 && X != 9) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (X != 9) __syncthreads();
       }
-      if (t < W4UNITS) load(L, t, ra[t % RING], rb[t % RING]);
-      else if (next) load(Ln, t - W4UNITS, ra[t % RING], rb[t % RING]);
+      if (X != 7 && X != 8 && X != 9) {
+        if (t < W4UNITS) load(L, t, ra[t % RING], rb[t % RING]);
+        else load(Ln, t - W4UNITS, ra[t % RING], rb[t % RING]);
+      }
+      // (one unit's reads at a time: left alone, hipcc merges the reads of two units into ds_read2st64_b64, which the LDS
+      // serves in 16-lane groups over 32 banks -- 2-way conflicts on this layout, 16 cycles for what two ds_read_b64 do
+      // in 4; SQ_LDS_BANK_CONFLICT 0.37 of the LDS cycles, -2.8 % per layer without them, same box)
+      __builtin_amdgcn_sched_barrier(0);
       constexpr int D0 = 6;
-      if (more && u >= D0 && u < D0 + 12) {
+      if (u >= D0 && u < D0 + 12) {
         __builtin_amdgcn_sched_barrier(0);
-        if (X != 4) dma(st + 2, dbuf, u - D0);
+        if (X != 4 && X != 8 && X != 9) dma(st2, dbuf, u - D0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (X != 5) {
-        if (first && u < PL) mma0(u % PL, ra[u % RING], rb[u % RING]);
-        else mma(u % PL, ra[u % RING], rb[u % RING]);
-      }
+      if (X != 5) mma(u % PL, ra[u % RING], rb[u % RING]);
     }
     buf = nbuf;
   };
-  using c12 = std::integral_constant<int, 12>;
-  using c6 = std::integral_constant<int, 6>;
-  using T_ = std::true_type;
-  using F_ = std::false_type;
-  if (X == 5) {
-#pragma unroll
-    for (int p = 0; p < 12; ++p) acc[p] = zero16;
-  }
 
-  f32x16 Y[16];      // Y[4 i' + j'] = output point (i', j') of the tile; complete after pass D
-  // ---- pass A: transform rows 1, 2
-  stage(0, c12{}, T_{}, T_{}, T_{});
-  for (int st = 1; st < 32; ++st) stage(st, c12{}, T_{}, T_{}, F_{});
-  {
-    f32x16 t1[4], t2[4];
-    w4_fold_row(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], t1);
-    w4_fold_row(acc[6], acc[7], acc[8], acc[9], acc[10], acc[11], t2);
+  // Y[4 i' + j'][q] = elements 2 q, 2 q + 1 (the C/D map's registers) of output point (i', j'); complete after the last pass
+  f32x2 Y[16][8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      Y[0 + j] = t1[j] + t2[j];      // S_j (goes into Y0 and Y2)
-      Y[4 + j] = t1[j] - t2[j];      // D_j (goes into Y1 and Y3)
-      asm volatile("" : "+v"(Y[0 + j]));      // pin the fold here: hipcc otherwise sinks it towards the epilogue and
-      asm volatile("" : "+v"(Y[4 + j]));      // keeps every pass's accumulators alive in scratch
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Y[k][q] = (f32x2){0.f, 0.f};
+  auto pair_of = [&](int p, int q) { return (f32x2){acc[p][2 * q], acc[p][2 * q + 1]}; };
+  // Six passes, one per transform row i: the K loop over that row's six planes, then Y[i'][:] += A^T[i'][i] (A^T M[i][:]).
+  // ONE loop body and ONE fold for the whole kernel; the row's weights A^T[0..3][i] are run-time scalars (exact: 0, +-1,
+  // +-2, 4, +-8).  96 accumulator registers beside the 256 of Y: nothing of either ever leaves the register file.
+#pragma unroll 1
+  for (int pass = 0; pass < 6; ++pass) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) acc[p] = zero16;
+#pragma unroll 1
+    for (int st = 0; st < 16; ++st) stage(16 * pass + st);
+    if (X != 6) {
+      //            i =  0   1   2   3   4   5
+      // A^T[0][i]      1   1   1   1   1   0
+      // A^T[1][i]      0   1  -1   2  -2   0
+      // A^T[2][i]      0   1   1   4   4   0
+      // A^T[3][i]      0   1  -1   8  -8   1
+      const float sgn = (pass & 1) ? 1.f : -1.f, mid = (pass >= 1 && pass <= 4) ? 1.f : 0.f, big = pass >= 3 ? 1.f : 0.f;
+      const float w0 = pass == 5 ? 0.f : 1.f;
+      const float w1 = mid * sgn * (1.f + big);              // 0 1 -1 2 -2 0
+      const float w2 = mid * (1.f + 3.f * big);              // 0 1 1 4 4 0
+      const float w3 = pass == 5 ? 1.f : mid * sgn * (1.f + 7.f * big);      // 0 1 -1 8 -8 1
+      const f32x2 wv[4] = {{w0, w0}, {w1, w1}, {w2, w2}, {w3, w3}};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        f32x2 t[4];
+        w4_fold_row(pair_of(0, q), pair_of(1, q), pair_of(2, q), pair_of(3, q), pair_of(4, q), pair_of(5, q), t);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            Y[4 * ii + jj][q] = __builtin_elementwise_fma(wv[ii], t[jj], Y[4 * ii + jj][q]);
+            // pin the fold here: hipcc otherwise sinks it towards the epilogue and keeps every pass's accumulators alive
+            asm volatile("" : "+v"(Y[4 * ii + jj][q]));
+          }
+        __builtin_amdgcn_sched_barrier(0);       // a pair at a time: interleaved, their temporaries crowd out the outputs
+      }
     }
+    W4_STAMP(3 + pass);
   }
-  // ---- pass B: rows 3, 4
-  stage(32, c12{}, T_{}, T_{}, T_{});
-  for (int st = 33; st < 64; ++st) stage(st, c12{}, T_{}, T_{}, F_{});
-  {
-    f32x16 t3[4], t4[4];
-    w4_fold_row(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], t3);
-    w4_fold_row(acc[6], acc[7], acc[8], acc[9], acc[10], acc[11], t4);
+  if (X == 6) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x16 s = t3[j] + t4[j], d = t3[j] - t4[j];
-      const f32x16 S = Y[0 + j], D = Y[4 + j];
-      Y[0 + j] = S + s;
-      Y[4 + j] = D + 2.f * d;
-      Y[8 + j] = S + 4.f * s;
-      Y[12 + j] = D + 8.f * d;
-      asm volatile("" : "+v"(Y[0 + j]));
-      asm volatile("" : "+v"(Y[4 + j]));
-      asm volatile("" : "+v"(Y[8 + j]));
-      asm volatile("" : "+v"(Y[12 + j]));
-    }
-  }
-  // ---- pass C: row 0
-  stage(64, c6{}, T_{}, T_{}, T_{});
-  for (int st = 65; st < 80; ++st) stage(st, c6{}, T_{}, T_{}, F_{});
-  {
-    f32x16 t0[4];
-    w4_fold_row(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], t0);
+    for (int k = 0; k < 16; ++k)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      Y[0 + j] += t0[j];
-      asm volatile("" : "+v"(Y[0 + j]));
-    }
-  }
-  // ---- pass D: row 5
-  stage(80, c6{}, T_{}, T_{}, T_{});
-  for (int st = 81; st < W4NST - 2; ++st) stage(st, c6{}, T_{}, T_{}, F_{});
-  stage(W4NST - 2, c6{}, F_{}, T_{}, F_{});
-  stage(W4NST - 1, c6{}, F_{}, F_{}, F_{});
-  {
-    f32x16 t5[4];
-    w4_fold_row(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], t5);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      Y[12 + j] += t5[j];
-      asm volatile("" : "+v"(Y[12 + j]));
-    }
+      for (int q = 0; q < 8; ++q) Y[k][q] = pair_of(k % 6, q);
   }
   if (X == 1) {
     float keep = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) keep += Y[k][0] + Y[k][15];
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) keep += Y[k][q][0] + Y[k][q][1];
     if (keep == 123.456f) y[0] = keep;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
 
+  // Everything the epilogue derives from the thread id or from its pointer arguments is derived HERE, from opaque copies:
+  // left to itself hipcc hoists that arithmetic (and the affine's loads) above the K loops, keeps ~60 registers of it alive
+  // through them and parks running outputs in scratch to make room -- and a scratch reload is an s_waitcnt vmcnt(0), which
+  // waits for every LDS-DMA piece in flight.
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  const float *scale_e = scale, *shift_e = shift, *res_e = res;
+  float *y_e = y, *vnext_e = vnext;
+  asm volatile("" : "+s"(scale_e), "+s"(shift_e), "+s"(res_e), "+s"(y_e), "+s"(vnext_e));
+  const int lane_e = tid_e & 63;
+  const int wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6);
+  const int wm_e = wave_e & 1, wn_e = wave_e >> 1;
+  const int l31_e = lane_e & 31, hi_e = lane_e >> 5;
   // ---- epilogue, once per half of the 64 couts (registers 8 hh .. 8 hh + 7 of every tuple = couts 32 hh .. 32 hh + 31).
   // Half image img[X][8 units of 16 B], X = k * 64 + tile row; unit u of row X sits at slot u ^ ((X >> 1) & 7): the 16
   // lanes of a ds_read_b128 group (consecutive rows) then cover 64 banks once, and an LDS-DMA instruction fills eight
-  // rows (1 KB), each lane choosing the global 16 B that belong in its slot.
+  // rows (1 KB), each lane_e choosing the global 16 B that belong in its slot.
   float* img = lds;
-  
-  const int trow = wm * 32 + l31;                       // this lane's tile row
+  const int trow = wm_e * 32 + l31_e;                       // this lane_e's tile row
   float sc[16], sh[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
-    const int co = cb * W4C + (i >> 4) * 32 + wn * 16 + (i & 15);
-    sc[e] = scale[co];
-    sh[e] = shift[co];
+    const int i = (e & 3) + 8 * (e >> 2) + 4 * hi_e;
+    const int co = cb * W4C + (i >> 4) * 32 + wn_e * 16 + (i & 15);
+    sc[e] = scale_e[co];
+    sh[e] = shift_e[co];
   }
   const float relu_lo = relu ? 0.f : -3.0e38f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                       // every wave has left the K loop: the stage buffers are dead
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the wrapped-around DMA of the last two stages included)
+  __syncthreads();                                       // every wave_e has left the K loop: the stage buffers are dead
 
-  auto half = [&](auto hh_c) {
-    constexpr int hh = decltype(hh_c)::value;
-    if (res) {
-      // instruction n of wave w fills image rows 8 (w + 4 n) .. + 7: lane = (row X, slot s) fetches unit s ^ ((X >> 1) & 7)
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    if (RES) {
+      // instruction n of wave_e w fills image rows 8 (w + 4 n) .. + 7: lane_e = (row X, slot s) fetches unit s ^ ((X >> 1) & 7)
 #pragma unroll 4
       for (int n = 0; n < 32; ++n) {
-        const int i = wave + 4 * n;
-        const int Xp = 8 * i + (lane >> 3), u = (lane & 7) ^ ((Xp >> 1) & 7);
+        const int i = wave_e + 4 * n;
+        const int Xp = 8 * i + (lane_e >> 3), u = (lane_e & 7) ^ ((Xp >> 1) & 7);
         const int off = ptab[Xp];
         const unsigned boff = off >= 0 ? 4u * (unsigned)(off + hh * W4CP + 4 * u) : 0u;
-        glds16s(res, boff, lds0 + (unsigned)(i * 256) * 4u);
+        glds16s(res_e, boff, lds0 + (unsigned)(i * 256) * 4u);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual half-tile has landed, for every wave
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual half-tile has landed, for every wave_e
       __syncthreads();
     }
-    // img = ReLU(img (the residual) + scale * value + shift): the lane's two register quads of this half for each of the
-    // 16 output points; unit wn * 4 + 2 qd + hi of row X = k * 64 + trow
+    // img = ReLU(img (the residual) + scale_e * value + shift_e): the lane_e's two register quads of this half (registers
+    // 0..7: the second half's were moved down) for each of the 16 output points; unit wn_e * 4 + 2 qd + hi_e of row X = k * 64 + trow
     {
       const unsigned rowb = lds0 + 4u * (unsigned)(trow * W4CP);
       const int swz = (trow >> 1) & 7;                   // (X >> 1) & 7 = (trow >> 1) & 7: k * 64 does not reach bits 1..3
-      const unsigned a0 = rowb + 16u * (unsigned)((wn * 4 + hi) ^ swz), a1 = rowb + 16u * (unsigned)((wn * 4 + 2 + hi) ^ swz);
+      const unsigned a0 = rowb + 16u * (unsigned)((wn_e * 4 + hi_e) ^ swz), a1 = rowb + 16u * (unsigned)((wn_e * 4 + 2 + hi_e) ^ swz);
 #pragma unroll
       for (int k0 = 0; k0 < 16; k0 += 4) {
         f32x4 rr[4][2];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const unsigned kb = 4u * (unsigned)((k0 + kk) * W4T * W4CP);
-          rr[kk][0] = res ? *(const __attribute__((address_space(3))) f32x4*)(size_t)(a0 + kb) : (f32x4){0.f, 0.f, 0.f, 0.f};
-          rr[kk][1] = res ? *(const __attribute__((address_space(3))) f32x4*)(size_t)(a1 + kb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (RES) {
+            rr[kk][0] = *(const __attribute__((address_space(3))) f32x4*)(size_t)(a0 + kb);
+            rr[kk][1] = *(const __attribute__((address_space(3))) f32x4*)(size_t)(a1 + kb);
+          } else {
+            rr[kk][0] = rr[kk][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -470,9 +513,8 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
             f32x4 v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              constexpr int e0 = 8 * hh;
-              const int e = e0 + 4 * qd + c;
-              v[c] = fmaxf(__builtin_fmaf(Y[k0 + kk][e], sc[e], sh[e]) + rr[kk][qd][c], relu_lo);
+              const int e = 4 * qd + c;
+              v[c] = fmaxf(__builtin_fmaf(Y[k0 + kk][e >> 1][e & 1], sc[e], sh[e]) + rr[kk][qd][c], relu_lo);
             }
             *(__attribute__((address_space(3))) f32x4*)(size_t)((qd ? a1 : a0) + kb) = v;
           }
@@ -480,14 +522,15 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
       }
     }
     __syncthreads();
+    W4_STAMP(10 + 4 * hh);
 
     if (MODE & 1) {
-      // image -> y: 8 consecutive lanes cover the 128 contiguous bytes of one output point's half; thread tid handles
-      // points X = (tid >> 3) + 32 i, always slot tid & 7 = unit (tid & 7) ^ ((tid >> 4) & 7) (32 i does not reach bits 1..3)
-      const int cg4 = hh * W4CP + 4 * ((tid & 7) ^ ((tid >> 4) & 7));
-      const f32x4* ip0 = reinterpret_cast<const f32x4*>(img) + tid;
-      const int* pt0 = ptab + (tid >> 3);
-#pragma unroll
+      // image -> y_e: 8 consecutive lanes cover the 128 contiguous bytes of one output point's half; thread tid_e handles
+      // points X = (tid_e >> 3) + 32 i, always slot tid_e & 7 = unit (tid_e & 7) ^ ((tid_e >> 4) & 7) (32 i does not reach bits 1..3)
+      const int cg4 = hh * W4CP + 4 * ((tid_e & 7) ^ ((tid_e >> 4) & 7));
+      const f32x4* ip0 = reinterpret_cast<const f32x4*>(img) + tid_e;
+      const int* pt0 = ptab + (tid_e >> 3);
+#pragma unroll 1
       for (int i0 = 0; i0 < 32; i0 += 8) {
         f32x4 v[8];
         int offs[8];
@@ -498,14 +541,15 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (offs[j] >= 0) *reinterpret_cast<f32x4*>(y + offs[j] + cg4) = v[j];
+          if (offs[j] >= 0) *reinterpret_cast<f32x4*>(y_e + offs[j] + cg4) = v[j];
       }
     }
 
+    W4_STAMP(11 + 4 * hh);
     if ((MODE & 2) && X != 2) {
       // ---- the next layer's input transform for this half's 32 channels = 8 channel groups (groups cb * 16 + hh * 8 + g
-      // of the next layer's 64).  Task = (tile row, group): lane = row, wave w takes groups w and w + 4.
-      const int row = lane;
+      // of the next layer's 64).  Task = (tile row, group): lane_e = row, wave_e w takes groups w and w + 4.
+      const int row = lane_e;
       const long tile = (long)tb * RPB + row;
       const bool live = row < RPB && tile < Mt;
       const int t = live ? (int)(tile % TT) : 0;
@@ -513,9 +557,9 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
       const bool emit = w4_whole_boards(T) || (live && w4_tile_fused(T, row, ti, tj));
       // Patch point (u, v) of tile (ti, tj) is board point (4 ti - 1 + u, 4 tj - 1 + v): output (ku, kv) of the tile du
       // tile rows / dv tiles further on, (du, ku) = (-1, 3), (0, 0..3), (1, 0) for u = 0..5.  A point off the board (or a
-      // lane that emits nothing) reads a block of zeros instead of being masked out.  adr[q]: LDS byte address of the
-      // point's unit for group `wave` (+ the lane's pair order: rows with bit 4 set store pair 1 first, so they read it
-      // first); group wave + 4 is the same address with bit 6 flipped (slot ^ 4) -- also inside the 256-byte zeros block.
+      // lane_e that emits nothing) reads a block of zeros instead of being masked out.  adr[q]: LDS byte address of the
+      // point's unit for group `wave_e` (+ the lane_e's pair order: rows with bit 4 set store pair 1 first, so they read it
+      // first); group wave_e + 4 is the same address with bit 6 flipped (slot ^ 4) -- also inside the 256-byte zeros block.
       unsigned adr[36];
       const unsigned zadr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&zeros[0];
 #pragma unroll
@@ -527,32 +571,28 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
           const int pi = 4 * ti - 1 + u, pj = 4 * tj - 1 + v;
           const bool ok = live && emit && pi >= 0 && pi < N && pj >= 0 && pj < N;
           const int Xq = (ku * 4 + kv) * W4T + row + du * T + dv;
-          adr[u * 6 + v] = ok ? lds0 + 4u * (unsigned)(Xq * W4CP + 4 * (wave ^ ((Xq >> 1) & 7)) + 2 * ((row >> 4) & 1)) : zadr;
+          adr[u * 6 + v] = ok ? lds0 + 4u * (unsigned)(Xq * W4CP + 4 * (wave_e ^ ((Xq >> 1) & 7)) + 2 * ((row >> 4) & 1)) : zadr;
         }
 #pragma unroll 1
       for (int it = 0; it < 2; ++it) {
-        const int g = wave + 4 * it;
+        const int g = wave_e + 4 * it;
         const unsigned xo = (unsigned)it << 6;
-        f32x4 d[36];
-#pragma unroll
-        for (int q = 0; q < 36; ++q) {
-          const unsigned a0 = adr[q] ^ xo;
-          const f32x2 a = *(const __attribute__((address_space(3))) f32x2*)(size_t)a0;
-          const f32x2 b = *(const __attribute__((address_space(3))) f32x2*)(size_t)(a0 ^ 8u);
-          d[q] = (f32x4){a[0], a[1], b[0], b[1]};
-        }
         const int c = cb * 16 + hh * 8 + g;               // the next layer's channel group
-        float* gbase = vnext + (long)tb * W4BLOCK + row * 4;
+        float* gbase = vnext_e + (long)tb * W4BLOCK + row * 4;
+        // one channel pair at a time (the lane_e's first pair in ITS row's order, then the second: the reads' ^ 8), so that
+        // the 36 patch values, their half-transformed form and one pair's results are all that is live beside the outputs
         f32x2 vv[36][2];
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
+          f32x2 d[36];
+#pragma unroll
+          for (int q = 0; q < 36; ++q)
+            d[q] = *(const __attribute__((address_space(3))) f32x2*)(size_t)((adr[q] ^ xo) ^ (hp ? 8u : 0u));
           f32x2 tx[36];
 #pragma unroll
           for (int v = 0; v < 6; ++v) {
-            f32x2 r[6], cc[6];
-#pragma unroll
-            for (int u = 0; u < 6; ++u) cc[u] = (f32x2){d[u * 6 + v][2 * hp], d[u * 6 + v][2 * hp + 1]};
-            bt6<f32x2>(cc[0], cc[1], cc[2], cc[3], cc[4], cc[5], r);
+            f32x2 r[6];
+            bt6<f32x2>(d[0 * 6 + v], d[1 * 6 + v], d[2 * 6 + v], d[3 * 6 + v], d[4 * 6 + v], d[5 * 6 + v], r);
 #pragma unroll
             for (int i = 0; i < 6; ++i) tx[i * 6 + v] = r[i];
           }
@@ -563,28 +603,42 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
 #pragma unroll
             for (int j = 0; j < 6; ++j) vv[i * 6 + j][hp] = r[j];
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        // (the channel group's stage / unit bases: rows 1..4 live in stages c >> 1 (+ 32), rows 0 and 5 in 64 / 80 + (c >> 2))
-        const int base12 = (c >> 1) * W4HALF + (c & 1) * 12 * W4UNIT, base6 = (c >> 2) * W4HALF + (c & 3) * 6 * W4UNIT;
+        // (plane (i, j) of channel group c: stage 16 i + (c >> 2), unit (c & 3) * 6 + j)
+        const int cbase = (c >> 2) * W4HALF + (c & 3) * 6 * W4UNIT;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            const int o = (i == 1 || i == 2) ? base12 + ((i - 1) * 6 + j) * W4UNIT
-                        : (i == 3 || i == 4) ? 32 * W4HALF + base12 + ((i - 3) * 6 + j) * W4UNIT
-                        : i == 0 ? 64 * W4HALF + base6 + j * W4UNIT : 80 * W4HALF + base6 + j * W4UNIT;
+            const int o = cbase + i * 16 * W4HALF + j * W4UNIT;
             const f32x2 p0 = vv[i * 6 + j][0], p1 = vv[i * 6 + j][1];
             const f32x4 v4 = {p0[0], p0[1], p1[0], p1[1]};      // (already in the row's pair order: see the reads above)
             f32x4* gp = reinterpret_cast<f32x4*>(gbase + o);
+            if (X == 3) {
+              if (v4[0] + v4[3] == 123.456f) *gp = v4;
+              continue;
+            }
             if (emit) __builtin_nontemporal_store(v4, gp);
           }
       }
     }
-  };
-  half(std::integral_constant<int, 0>{});
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stores and loads share vmcnt: nothing of the first half is counted into the second half's residual wait)
-  __syncthreads();                                   // every wave has left the image: the second half may overwrite it
-  half(std::integral_constant<int, 1>{});
+    W4_STAMP(12 + 4 * hh);
+    if (hh == 0) {
+      // the second half runs this same code: its registers (8..15 of every tuple, and of the affine) move down
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Y[k][q] = Y[k][4 + q];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[e] = sc[8 + e];
+        sh[e] = sh[8 + e];
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stores and loads share vmcnt: nothing of the first half is counted into the second half's residual wait)
+      __syncthreads();                                   // every wave_e has left the image: the second half may overwrite it
+    }
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -638,7 +692,7 @@ void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, 
   const int blocks = (int)wino4_blocks(bcap, T);
   wino4_check(bcap, N);
   if (fixup) {
-    AGZ_REQUIRE(!w4_whole_boards(T), AGZ_BAD_ARGUMENT, "fix-up transform: dense tile blocks only");
+    AGZ_REQUIRE(!w4_whole_boards(T) && T + 1 <= 8, AGZ_BAD_ARGUMENT, "fix-up transform: dense tile blocks, at most 8 rows at a block's ends");
     hipLaunchKernelGGL((k_wino4_in<true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
   } else {
     hipLaunchKernelGGL((k_wino4_in<false>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
@@ -653,20 +707,47 @@ void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale,
   const int per_xcd = 4 * ((blocks + 7) / 8);
   const dim3 grid(8 * per_xcd), block(256);
   wino4_check(bcap, N);
+  AGZ_REQUIRE(y || vnext, AGZ_BAD_ARGUMENT, "F(4x4,3x3) GEMM: nothing to write");
+#define W4_LAUNCH(MODE_, X_) hipLaunchKernelGGL((k_wino4_gemm<MODE_, X_>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu)
 #ifdef AGZ_TIMING_EXPERIMENTS
   static const int xp = getenv("AGZ_WINO4_X") ? atoi(getenv("AGZ_WINO4_X")) : 0;
-  if (xp && y && vnext) {
-    auto kern = xp == 1 ? k_wino4_gemm<3, 1> : xp == 2 ? k_wino4_gemm<3, 2> : xp == 4 ? k_wino4_gemm<3, 4> : xp == 5 ? k_wino4_gemm<3, 5> : k_wino4_gemm<3, 0>;
-    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+  static int traced = 0;
+  if (getenv("AGZ_WINO4_TRACE") && y && vnext && res && ++traced == 3) {      // third steady-state conv2-form launch
+    W4_LAUNCH(7, 0);
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[8192][20];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(w4_trace), sizeof(host));
+    if (FILE* f = fopen(getenv("AGZ_WINO4_TRACE"), "wb")) {
+      fwrite(host, 1, sizeof(host), f);
+      fclose(f);
+    }
     return;
   }
+  if (xp && y && vnext && res) {
+    switch (xp) {
+      case 1: W4_LAUNCH(7, 1); return;
+      case 2: W4_LAUNCH(7, 2); return;
+      case 3: W4_LAUNCH(7, 3); return;
+      case 4: W4_LAUNCH(7, 4); return;
+      case 5: W4_LAUNCH(7, 5); return;
+      case 6: W4_LAUNCH(7, 6); return;
+      case 7: W4_LAUNCH(7, 7); return;
+      case 8: W4_LAUNCH(7, 8); return;
+      case 9: W4_LAUNCH(7, 9); return;
+      default: break;
+    }
+  }
 #endif
-  if (y && vnext)
-    hipLaunchKernelGGL((k_wino4_gemm<3, 0>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
-  else if (vnext)
-    hipLaunchKernelGGL((k_wino4_gemm<2, 0>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
-  else
-    hipLaunchKernelGGL((k_wino4_gemm<1, 0>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+  const int mode = (y ? 1 : 0) | (vnext ? 2 : 0) | (res ? 4 : 0);
+  switch (mode) {
+    case 1: W4_LAUNCH(1, 0); break;
+    case 2: W4_LAUNCH(2, 0); break;
+    case 3: W4_LAUNCH(3, 0); break;
+    case 5: W4_LAUNCH(5, 0); break;
+    case 6: W4_LAUNCH(6, 0); break;
+    default: W4_LAUNCH(7, 0); break;
+  }
+#undef W4_LAUNCH
 }
 
 }  // namespace agz
