@@ -37,15 +37,22 @@ def f_eval(N, t):
     return 2.0 * P * (9 * 17 * 256 + t * 2 * 9 * 256 * 256) + 2.0 * P * 256 * 3 + 2.0 * (2 * P * (P + 1) + P * 256 + 256)
 
 
-def pmc_traffic(rows_per_launch, N, precision="f32"):
+def pmc_traffic(rows_per_launch, N, precision="f32", f43=False):
     """HBM bytes per tower-conv launch, from the committed rocprofv3 --pmc passes.
 
     Hardware counters cannot be read from inside this process; FETCH_SIZE and WRITE_SIZE were collected in two
-    separate `rocprofv3 --pmc` runs of THIS command (tools/profile_r03.sh: same kernels, same batch) and summarised
+    separate `rocprofv3 --pmc` runs of THIS command (tools/profile_r04.sh: same kernels, same batch) and summarised
     by tools/pmc_traffic.py as bytes per board-point row.  Scaled here by the average rows per launch of THIS run.
-    None if no file exists for the board size and precision."""
-    for name in (f"r03_pmc_traffic_{N}x{N}_{precision}.json",) + (
-            ("pmc_traffic.json" if precision == "f32" else f"r02_pmc_traffic_{precision}.json",) if N == 9 else ()):
+    The newest round's file for the board size and precision wins; the F(4x4,3x3) tower (19x19 f32 since round 4) only
+    takes a round-4 file.  None if no file exists."""
+    names = [f"r04_pmc_traffic_{N}x{N}_{precision}.json"]
+    if not f43:
+        names.append(f"r03_pmc_traffic_{N}x{N}_{precision}.json")
+        if N == 9:
+            names.append("pmc_traffic.json" if precision == "f32" else f"r02_pmc_traffic_{precision}.json")
+    if N >= 13 and precision == "f32" and not f43:
+        names = names[1:]              # (--winograd 2 on a large board: the round-3 kernel's file)
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         try:
             d = json.load(open(path))
@@ -489,7 +496,7 @@ def main():
         T4 = (N + 3) // 4
         wino_ratio = 1.0 if f16 else (36.0 * T4 * T4 / (9.0 * N * N) if f43 else 25.0 * T * T / (9.0 * N * N))
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), N, args.precision)
+        traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), N, args.precision, f43)
         # The roofline object.  `achieved`/`frac` are what the MFMA pipe EXECUTES: Winograd F(3x3,3x3) needs 25
         # multiplies per 3x3 output tile and (cin, cout) pair instead of 81, all of them still f32, so the
         # honest fraction of the f32 MFMA peak is executed flops / time / peak (<= 1).  The rate in terms of the
