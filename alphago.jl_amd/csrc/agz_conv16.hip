@@ -115,6 +115,11 @@ void conv16_pack_images(const ConvHost& c, uint16_t* out) {
                 w[((size_t)st * kC + cb * 32 + (lane & 31)) * HK + (ks * 2 + (lane >> 5)) * 8 + k];
 }
 
+#ifdef AGZ_TIMING_EXPERIMENTS
+// pacing experiment: bit i set = the waves sleep 64 clocks in k-step i of every channel chunk (AGZ_C16_PACE, 18 bits)
+__device__ unsigned g_c16_pace = 0;
+#endif
+
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < E) {
@@ -125,7 +130,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // RES: 0 = no residual, 1 = half, 2 = f32 (first block's skip); OUTF: the output is f32 (last layer), else half.
 // DBG (timing variants, -DAGZ_TIMING_EXPERIMENTS, wrong results): bit mask of what is compiled out -- 1 epilogue,
-// 2 weight loads, 4 LDS operand reads, 8 slab DMA, 16 MFMA, 32 result stores.
+// 2 weight loads, 4 LDS operand reads, 8 slab DMA, 16 MFMA, 32 result stores; 64 = the stores go to 64 fixed (L2-resident)
+// regions; 128 = non-temporal result stores.
 // RB: row blocks of 32 per tile -- 7 (one workgroup per CU, results leave through the LDS image) or 4 (two workgroups
 // per CU, direct epilogue)
 template <int DBG, int RES, bool OUTF, int RB>
@@ -221,8 +227,13 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   const char* wfw = reinterpret_cast<const char*>(wf) + wave * 2048;
   auto load_b = [&](int slot, const char* wbase, int kk) __attribute__((always_inline)) {   // this wave's two fragments of k-step kk
     const char* p = wbase + (size_t)kk * 8192;
-    Bf[slot][0] = *reinterpret_cast<const h8*>(p + wlane);
-    Bf[slot][1] = *reinterpret_cast<const h8*>(p + 1024 + wlane);
+    if (DBG & 256) {      // (timing variant: streaming weight loads)
+      Bf[slot][0] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(p + wlane));
+      Bf[slot][1] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(p + 1024 + wlane));
+    } else {
+      Bf[slot][0] = *reinterpret_cast<const h8*>(p + wlane);
+      Bf[slot][1] = *reinterpret_cast<const h8*>(p + 1024 + wlane);
+    }
   };
 
   // Result image of the workgroup: [pass 7][32 rows][512 B], a row's thirty-two 16-byte pieces swizzled by the row
@@ -297,6 +308,9 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   };
 
   // one channel chunk: 9 taps x 2 k-steps of 14 MFMAs.  FIRST / LAST chunk of a tile are compile-time.
+#ifdef AGZ_TIMING_EXPERIMENTS
+  const unsigned pace_mask = __builtin_amdgcn_readfirstlane(g_c16_pace);
+#endif
   auto chunk = [&](int cc, auto firstc, auto lastc) __attribute__((always_inline)) {
     constexpr bool first = decltype(firstc)::value, last = decltype(lastc)::value;
     const int sbuf = cc & 1;
@@ -317,6 +331,9 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
       }
       int kn = cc * 18 + i + W2_D;
       kn = kn >= W2_KS ? kn - W2_KS : kn;
+#ifdef AGZ_TIMING_EXPERIMENTS
+      if (pace_mask & (1u << i)) __builtin_amdgcn_s_sleep(1);
+#endif
 #pragma unroll
       for (int mi = 0; mi < 2 * W2_RB; ++mi) {
         const int rbk = mi >> 1, cb = mi & 1;
@@ -339,7 +356,11 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
         // chunk cc sends pass cc of the previous tile's image on its way: piece i / 4, read one k-step before it is stored
         if (TRICKLE && !last && !(DBG & 33) && mi == 12) {
           if constexpr (i % 4 == 2) treg = *reinterpret_cast<const u4*>(outw + cc * 16384 + tl[i / 4]);
-          if constexpr (i % 4 == 3) *reinterpret_cast<u4*>(yprev + (size_t)cc * (32 * kC * 2) + (i / 4) * 4096 + tg) = treg;
+          if constexpr (i % 4 == 3) {
+            u4* gp = reinterpret_cast<u4*>(yprev + (size_t)cc * (32 * kC * 2) + (i / 4) * 4096 + tg);
+            if (DBG & 128) __builtin_nontemporal_store(treg, gp);      // (timing variant)
+            else *gp = treg;
+          }
         }
         if (last && RES != 0 && !(DBG & 1) && mi == 2 * RB - 2) {  // the first passes' residual, spread over the last chunk
           if (i == 4) load_res(std::integral_constant<int, 0>{});
@@ -406,7 +427,8 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
         asm volatile("" ::: "memory");
       };
       static_for<0, W2_RB>(pass);
-      yprev = reinterpret_cast<char*>(y) + (size_t)m0 * (kC * 2);
+      // (timing variant 64: every tile's image leaves for one of 64 fixed tile-sized regions -- the stores stay in L2)
+      yprev = reinterpret_cast<char*>(y) + ((DBG & 64) ? (size_t)(blockIdx.x & 63) * W2_HM : (size_t)m0) * (kC * 2);
       __syncthreads();                                      // the image is complete: any wave may send any row
     } else {
       // direct: residual and result cross a wave-private LDS tile each, so that HBM sees 16-byte pieces of whole rows
@@ -516,6 +538,12 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   // timing experiments only (make EXTRA=-DAGZ_TIMING_EXPERIMENTS, tools/c16_x.sh): AGZ_C16_DEBUG = bit mask of what is
   // compiled out (wrong results), AGZ_C16_RB=4 = 128-row tiles, two workgroups per CU, direct epilogue
   static const int dbg = getenv("AGZ_C16_DEBUG") ? atoi(getenv("AGZ_C16_DEBUG")) : 0;
+  static bool pace_set = false;
+  if (!pace_set) {
+    pace_set = true;
+    const unsigned pm = getenv("AGZ_C16_PACE") ? (unsigned)strtoul(getenv("AGZ_C16_PACE"), nullptr, 0) : 0u;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_c16_pace), &pm, sizeof(pm));
+  }
   static const int rb = getenv("AGZ_C16_RB") ? atoi(getenv("AGZ_C16_RB")) : W2_RB_PRODUCT;
   if (rb == 4) {
     AGZ_C16_W2D(0, 4, std::min((int)((rows + 127) / 128), 2 * ncu));
@@ -528,6 +556,13 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
     case 9: AGZ_C16_W2D(9, W2_RB_PRODUCT, grid7); return;
     case 15: AGZ_C16_W2D(15, W2_RB_PRODUCT, grid7); return;
     case 32: AGZ_C16_W2D(32, W2_RB_PRODUCT, grid7); return;
+    case 16: AGZ_C16_W2D(16, W2_RB_PRODUCT, grid7); return;
+    case 48: AGZ_C16_W2D(48, W2_RB_PRODUCT, grid7); return;
+    case 64: AGZ_C16_W2D(64, W2_RB_PRODUCT, grid7); return;
+    case 128: AGZ_C16_W2D(128, W2_RB_PRODUCT, grid7); return;
+    case 256: AGZ_C16_W2D(256, W2_RB_PRODUCT, grid7); return;
+    case 34: AGZ_C16_W2D(34, W2_RB_PRODUCT, grid7); return;
+    case 2: AGZ_C16_W2D(2, W2_RB_PRODUCT, grid7); return;
     default: break;
   }
 #endif
