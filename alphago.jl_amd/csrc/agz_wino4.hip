@@ -86,14 +86,27 @@ __host__ __device__ __forceinline__ int w4_off(int row, int h) { return row * 4 
 // the next layer's K loop).
 __host__ __device__ __forceinline__ int w4_cout_of_urow(int r) { return (((r & 31) >> 4) << 5) + ((r >> 5) << 4) + (r & 15); }
 
-// tile geometry (shared with agz_wino.hip's rules, for T = ceil(N / 4)): whole boards per 64-row block when they pack
-// with <= 10 % waste (T*T = 16: N = 13..16), else dense packing
-__host__ __device__ inline int w4_rows_per_block(int T) {
+// Tile geometry, T = ceil(N / 4) tiles per side.  Tiles are numbered board by board (tile = board * T*T + ti * T + tj) and
+// a block holds consecutive tiles, so a tile's neighbours (ti + di, tj + dj) are rows row + di T + dj of its block -- if
+// they are in its block.  Three packings:
+//   * whole boards per 64-row block when they pack with <= 10 % waste (T*T = 16, N = 13..16: 4 boards per block);
+//   * T*T = 25 (N = 17..19): FIVE boards in TWO blocks (64 + 61 rows, 3 dead rows in 128: 2.3 %), so that only one of two
+//     block boundaries cuts a board -- half the tiles whose patch straddles a boundary, half the fix-up transform;
+//   * otherwise dense: block tb starts at tile 64 tb.
+__host__ __device__ inline int w4_rows_per_block(int T) {      // whole-board packing: rows that carry tiles; else 64
   const int tt = T * T;
   const int whole = (W4T / tt) * tt;
   return (tt <= W4T && whole * 10 >= W4T * 9) ? whole : W4T;
 }
 __host__ __device__ inline bool w4_whole_boards(int T) { return w4_rows_per_block(T) % (T * T) == 0 && T * T <= W4T; }
+__host__ __device__ __forceinline__ bool w4_paired(int T) { return T * T == 25; }
+// first tile of block tb / rows of it that can carry tiles
+__host__ __device__ __forceinline__ long w4_block_base(int T, int tb) {
+  return w4_paired(T) ? (long)(tb >> 1) * 125 + (tb & 1) * W4T : (long)tb * w4_rows_per_block(T);
+}
+__host__ __device__ __forceinline__ int w4_block_rows(int T, int tb) {
+  return w4_paired(T) ? ((tb & 1) ? 125 - W4T : W4T) : w4_rows_per_block(T);
+}
 // dense blocks: is the 6x6 input patch of tile (ti, tj) in row `row` made of tiles of the same block?  (its neighbours
 // (ti + di, tj + dj) are rows row + di T + dj)
 __host__ __device__ __forceinline__ bool w4_tile_fused(int T, int row, int ti, int tj) {
@@ -141,19 +154,22 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   constexpr int IMG = 36 * CH + 8;               // stride between the groups' copies (+8: bank skew of the 8-byte writes)
   __shared__ __attribute__((aligned(16))) float img[GP * IMG];
   const int P = N * N, TT = T * T;
-  const int RPB = w4_rows_per_block(T);
   const long Mt = (long)(*d_count) * TT;
   const int tb = blockIdx.x >> 1, part = blockIdx.x & 1;
+  const int RPB = w4_block_rows(T, tb);
+  const long tbase = w4_block_base(T, tb);
   const int row0 = FIXUP ? part * (W4T - TPB) : part * TPB;      // first row of this workgroup
-  if ((long)tb * RPB + row0 >= Mt) return;
+  if (tbase + row0 >= Mt) return;
   const int hs = threadIdx.x % LPT, h = hs & 1, sl = hs >> 1;
   const int tl = threadIdx.x / LPT;
   const int row = row0 + tl;
-  const long tile = (long)tb * RPB + row;
+  const long tile = tbase + row;
   bool live = row < RPB && tile < Mt;
   const int b = live ? (int)(tile / TT) : 0, t = live ? (int)(tile % TT) : 0;
   const int ti = t / T, tj = t % T;
   if (FIXUP && live && w4_tile_fused(T, row, ti, tj)) live = false;       // in place already
+  // (paired packing: a block that starts or ends on a board boundary has nothing to fix at that end)
+  if (FIXUP && !__syncthreads_or(live)) return;
   int off[36];
 #pragma unroll
   for (int u = 0; u < 6; ++u)
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   bool copy_row = true;
   if (FIXUP) {      // only the rows this kernel computed leave (a dead row inside the range is written as zeros)
     const int crow = row0 + cl;
-    const long ctile = (long)tb * RPB + crow;
+    const long ctile = tbase + crow;
     const int ct = (int)(ctile % TT);
     copy_row = !(crow < RPB && ctile < Mt && w4_tile_fused(T, crow, ct / T, ct % T));
   }
@@ -257,7 +273,6 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   __shared__ __attribute__((aligned(256))) float zeros[64];      // what phase 2 reads for a patch point off the board
   constexpr bool RES = (MODE & 4) != 0;
   const int P = N * N, TT = T * T;
-  const int RPB = w4_rows_per_block(T);
   const long Mt = (long)(*d_count) * TT;
   // workgroup -> (tile block, cout block): the four cout blocks of a tile block are four consecutive workgroups of one
   // XCD (block b runs on XCD b % 8), so its V slab comes out of HBM once (agz_wino.hip's placement)
@@ -265,7 +280,9 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   const int xcd = bid & 7, jb = bid >> 3;
   const int cb = jb & 3;
   const int tb = xcd + 8 * (jb >> 2);
-  if ((long)tb * RPB >= Mt) return;
+  const int RPB = w4_block_rows(T, tb);
+  const long tbase = w4_block_base(T, tb);
+  if (tbase >= Mt) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   if (tid < 64) zeros[tid] = 0.f;
   for (int idx = tid; idx < W4T * 16; idx += 256) {     // (published by the barrier in front of the first operand reads)
     const int row = idx & (W4T - 1), k = idx >> 6;
-    const long tile = (long)tb * RPB + row;
+    const long tile = tbase + row;
     int off = -1;
     if (row < RPB && tile < Mt) {
       const unsigned tile32 = (unsigned)tile, b = tile32 / (unsigned)TT, t = tile32 - b * (unsigned)TT;
@@ -550,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
       // ---- the next layer's input transform for this half's 32 channels = 8 channel groups (groups cb * 16 + hh * 8 + g
       // of the next layer's 64).  Task = (tile row, group): lane_e = row, wave_e w takes groups w and w + 4.
       const int row = lane_e;
-      const long tile = (long)tb * RPB + row;
+      const long tile = tbase + row;
       const bool live = row < RPB && tile < Mt;
       const int t = live ? (int)(tile % TT) : 0;
       const int ti = t / T, tj = t % T;
@@ -673,6 +690,10 @@ void wino4_pack_weights(const ConvHost& c, float* out) {
 
 size_t wino4_weight_floats() { return (size_t)(kC / W4C) * W4BLOCK; }
 static long wino4_blocks(int bcap, int T) {
+  if (w4_paired(T)) {      // five boards per block pair; the last pair's second block exists only if it has a tile
+    const long pairs = bcap / 5, rest = (long)(bcap % 5) * 25;
+    return 2 * pairs + (rest > W4T ? 2 : rest > 0 ? 1 : 0);
+  }
   const long rpb = w4_rows_per_block(T);
   return ((long)bcap * T * T + rpb - 1) / rpb;
 }
