@@ -122,6 +122,7 @@ def load():
         "agz_net_time_conv": (i32, [E, i32, i32, f32p]),
         "agz_net_set_winograd": (i32, [E, i32]),
         "agz_net_set_tower_persistent": (i32, [E, i32]),
+        "agz_net_set_tower_streams": (i32, [E, i32]),
         "agz_net_set_precision": (i32, [E, i32]),
         "agz_profile_conv_enable": (i32, [E, i32]),
         "agz_profile_conv_read": (i32, [E, f64p, f64p, P(i64)]),

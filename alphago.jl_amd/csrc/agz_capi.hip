@@ -153,6 +153,12 @@ agz_status agz_net_set_winograd(agz_engine* e, int32_t on) {
 agz_status agz_net_set_tower_persistent(agz_engine* e, int32_t on) {
   return guard(e, [&](agz::Engine& E) { E.net().set_tower_persistent(on != 0); });
 }
+agz_status agz_net_set_tower_streams(agz_engine* e, int32_t n) {
+  return guard(e, [&](agz::Engine& E) {
+    AGZ_REQUIRE(n == 1 || n == 2, AGZ_BAD_ARGUMENT, "agz_net_set_tower_streams: 1 or 2");
+    E.net().set_tower_streams(n);
+  });
+}
 agz_status agz_net_set_precision(agz_engine* e, int32_t precision) {
   return guard(e, [&](agz::Engine& E) {
     AGZ_REQUIRE(precision == AGZ_PRECISION_F32 || precision == AGZ_PRECISION_F16 || precision == AGZ_PRECISION_F32S,

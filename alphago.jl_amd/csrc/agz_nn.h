@@ -53,6 +53,11 @@ class Net {
   // exact-f32 arithmetic), 2 = Winograd F(3x3,3x3) on every board size (A/B runs), 0 = the direct implicit GEMM
   void set_winograd(int mode) { winograd_ = mode != 0; wino_f33_only_ = mode == 2; }
   bool winograd() const { return winograd_; }
+  // the F(4x4,3x3) tower as TWO independent layer chains (the two halves of the batch's tile blocks) on two streams: the
+  // hardware scheduler interleaves their workgroups, the CUs stop marching through K loops and store bursts in lockstep
+  // (-5 % per forward at 19x19 / 2048 positions; outputs are bit-identical: same kernels, same rows).  1 = one chain.
+  void set_tower_streams(int n) { tower_streams_ = n >= 2 ? 2 : 1; }
+  int tower_streams() const { return tower_streams_; }
   bool use_wino4() const { return winograd_ && !wino_f33_only_ && precision_ == 0 && tower_ > 0 && wino4_applies(N_); }
   // the f32 Winograd tower as ONE persistent launch (k_wino_tower) instead of one launch per layer, where it applies
   // (whole-board tile blocks, 256 CUs with 32 resident workgroups per XCD); same arithmetic, same bits.  Off by
@@ -121,6 +126,9 @@ class Net {
   bool winograd_ = true, wino_f33_only_ = false;
   DevBuf<float> d_uwino4_;                     // F(4x4,3x3) transformed weights (agz_wino4.hip), packed when first used
   bool packed4_ = false;
+  int tower_streams_ = 2;
+  hipStream_t stream2_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DevBuf<float> d_uwino_s_, d_scale_s_;        // split form: weights as halves, scale x 1 / (operand scales)
   bool packed_split_ = false;
   DevBuf<float> d_uwino_, d_vimg_, d_vimg2_;   // transformed weights (stage images) / transformed activations (ping-pong)
@@ -218,10 +226,13 @@ void wino4_pack_weights(const ConvHost& c, float* out);
 size_t wino4_weight_floats();
 size_t wino4_v_floats(int bcap, int N);
 // x -> V (all tiles), or with fixup only the tiles the previous GEMM's epilogue could not emit (dense blocks)
-void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s, bool fixup);
+void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s, bool fixup, int part = 0,
+                     int parts = 1);
 // V, U -> y (if y != NULL) and / or the next layer's V (if vnext != NULL)
 void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
-                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s);
+                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s, int part = 0,
+                       int parts = 1);
+// (part / parts: the part-th of `parts` ranges of tile blocks, cut at board boundaries: ranges are independent layer chains)
 
 // fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged
 void conv16_pack_images(const ConvHost& c, uint16_t* out);

@@ -739,21 +739,51 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         launch_wino_gemm(vnxt, d_ustem_.p, d_scale_.p, d_shift_.p, nullptr, a, nullptr, d_count, bcap, N_, 1, false, stream_,
                          kWinoStemStages);
         launch_wino4_in(a, vcur, d_count, bcap, N_, stream_, false);
-        for (int blk = 0; blk < tower_; ++blk) {
-          const int l1 = 2 * blk, l2 = 2 * blk + 1;
-          const bool last = blk + 1 == tower_;
-          timed([&] {
-            launch_wino4_gemm(vcur, d_uwino4_.p + per4 * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, dense4 ? t : nullptr,
-                              vnxt, d_count, bcap, N_, 1, stream_);
-            if (dense4) launch_wino4_in(t, vnxt, d_count, bcap, N_, stream_, true);
-          });
-          timed([&] {
-            launch_wino4_gemm(vnxt, d_uwino4_.p + per4 * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, a, b, last ? nullptr : vcur,
-                              d_count, bcap, N_, 1, stream_);
-            if (dense4 && !last) launch_wino4_in(b, vcur, d_count, bcap, N_, stream_, true);
-          });
-          std::swap(a, b);
+        // Two chains on two streams when the batch is large enough to fill the chip twice over (>= 4 workgroup rounds
+        // per chain); the chains touch disjoint rows of the same buffers.
+        const int parts = (tower_streams_ == 2 && (long)bcap * ((N_ + 3) / 4) * ((N_ + 3) / 4) >= 4 * 64 * 64 * 2) ? 2 : 1;
+        if (parts == 2 && !stream2_) {
+          AGZ_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+          AGZ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+          AGZ_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         }
+        const bool pt = prof_on_ && prof_n_ < kProfMax;
+        if (parts == 2) {
+          if (pt) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);        // (the whole tower between one event pair)
+          AGZ_HIP(hipEventRecord(ev_fork_, stream_));
+          AGZ_HIP(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+        }
+        for (int part = 0; part < parts; ++part) {
+          hipStream_t st = part == 0 ? stream_ : stream2_;
+          float *pa = a, *pb = b, *vc = vcur, *vn = vnxt;
+          for (int blk = 0; blk < tower_; ++blk) {
+            const int l1 = 2 * blk, l2 = 2 * blk + 1;
+            const bool last = blk + 1 == tower_;
+            auto layer1 = [&] {
+              launch_wino4_gemm(vc, d_uwino4_.p + per4 * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, dense4 ? t : nullptr,
+                                vn, d_count, bcap, N_, 1, st, part, parts);
+              if (dense4) launch_wino4_in(t, vn, d_count, bcap, N_, st, true, part, parts);
+            };
+            auto layer2 = [&] {
+              launch_wino4_gemm(vn, d_uwino4_.p + per4 * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, pa, pb, last ? nullptr : vc,
+                                d_count, bcap, N_, 1, st, part, parts);
+              if (dense4 && !last) launch_wino4_in(pb, vc, d_count, bcap, N_, st, true, part, parts);
+            };
+            if (parts == 1) { timed(layer1); timed(layer2); }
+            else { layer1(); layer2(); }
+            std::swap(pa, pb);
+          }
+        }
+        if (parts == 2) {
+          AGZ_HIP(hipEventRecord(ev_join_, stream2_));
+          AGZ_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+          if (pt) {
+            (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
+            prof_mult_[prof_n_] = 2 * tower_;
+            prof_fwd_of_[prof_n_++] = prof_fwd_;
+          }
+        }
+        if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
       } else {
       if (stem_wino) {
         launch_wino_in(d_x32, vnxt, d_count, bcap, N_, split, stream_, kWinoStemStages);
@@ -890,6 +920,9 @@ Net::~Net() {
   for (auto e : prof_ev_) (void)hipEventDestroy(e);
   if (prof_counts_) (void)hipHostFree(prof_counts_);
   if (tower_err_) (void)hipHostFree(tower_err_);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
 }
 
 void Net::profile_enable(bool on) {

@@ -50,6 +50,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -146,7 +147,7 @@ __device__ __forceinline__ void bt6(V x0, V x1, V x2, V x3, V x4, V x5, V* r) {
 // 32 mostly idle tiles (the first form of this kernel: 0.30 ms per layer, a tenth of it); rows in place are not touched.
 template <bool FIXUP>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, float* __restrict__ vimg,
-                                                  const int* __restrict__ d_count, int N, int T) {
+                                                  const int* __restrict__ d_count, int N, int T, int tb0, int tb1) {
   constexpr int TPB = FIXUP ? 8 : 32;            // tile rows per workgroup
   constexpr int LPT = 256 / TPB;                 // lanes per tile: 8 / 32
   constexpr int GP = LPT / 2;                    // channel groups per pass: 4 / 16
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   __shared__ __attribute__((aligned(16))) float img[GP * IMG];
   const int P = N * N, TT = T * T;
   const long Mt = (long)(*d_count) * TT;
-  const int tb = blockIdx.x >> 1, part = blockIdx.x & 1;
+  const int tb = tb0 + (int)(blockIdx.x >> 1), part = blockIdx.x & 1;      // tile blocks [tb0, tb1) of the batch
+  if (tb >= tb1) return;
   const int RPB = w4_block_rows(T, tb);
   const long tbase = w4_block_base(T, tb);
   const int row0 = FIXUP ? part * (W4T - TPB) : part * TPB;      // first row of this workgroup
@@ -267,7 +269,7 @@ template <int MODE, int X>
 __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
+    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu, int tb0, int tb1) {
   __shared__ __attribute__((aligned(256))) float lds[3 * W4STAGE];      // 144 KB: stage buffers, then the half image
   __shared__ int ptab[W4T * 16];            // element offset of output point X = k * 64 + row in y / res, or -1
   __shared__ __attribute__((aligned(256))) float zeros[64];      // what phase 2 reads for a patch point off the board
@@ -279,7 +281,8 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   const int bid = blockIdx.x;
   const int xcd = bid & 7, jb = bid >> 3;
   const int cb = jb & 3;
-  const int tb = xcd + 8 * (jb >> 2);
+  const int tb = tb0 + xcd + 8 * (jb >> 2);      // this launch covers tile blocks [tb0, tb1) of the batch
+  if (tb >= tb1) return;
   const int RPB = w4_block_rows(T, tb);
   const long tbase = w4_block_base(T, tb);
   if (tbase >= Mt) return;
@@ -652,8 +655,9 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
         sc[e] = sc[8 + e];
         sh[e] = sh[8 + e];
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stores and loads share vmcnt: nothing of the first half is counted into the second half's residual wait)
-      __syncthreads();                                   // every wave_e has left the image: the second half may overwrite it
+      // every wave has left the image: the second half may overwrite it.  (No vmcnt wait here: the first half's stores
+      // read registers, not the image, and drain under the second half's residual DMA, whose own wait is vmcnt(0).)
+      __syncthreads();
     }
   }
 }
@@ -708,28 +712,42 @@ static void wino4_check(int bcap, int N) {
               "batch of %d positions at %dx%d: tile index / activation byte offset exceeds 32 bits", bcap, N, N);
 }
 
-void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s, bool fixup) {
+// part / parts: this launch covers the part-th of `parts` equal ranges of tile blocks (cut at block-pair boundaries, so that
+// no board straddles two ranges: a range's layers depend on nothing outside it, and ranges can run on different streams)
+static void wino4_range(int blocks, int part, int parts, int& tb0, int& tb1) {
+  AGZ_REQUIRE(parts >= 1 && part >= 0 && part < parts, AGZ_BAD_ARGUMENT, "block range %d of %d", part, parts);
+  const int per = ((blocks + parts - 1) / parts + 1) & ~1;      // even: whole block pairs
+  tb0 = std::min(blocks, part * per);
+  tb1 = part + 1 == parts ? blocks : std::min(blocks, tb0 + per);
+}
+
+void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s, bool fixup, int part, int parts) {
   const int T = (N + 3) / 4;
-  const int blocks = (int)wino4_blocks(bcap, T);
+  int tb0, tb1;
+  wino4_range((int)wino4_blocks(bcap, T), part, parts, tb0, tb1);
+  if (tb1 <= tb0) return;
   wino4_check(bcap, N);
   if (fixup) {
     AGZ_REQUIRE(!w4_whole_boards(T) && T + 1 <= 8, AGZ_BAD_ARGUMENT, "fix-up transform: dense tile blocks, at most 8 rows at a block's ends");
-    hipLaunchKernelGGL((k_wino4_in<true>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+    hipLaunchKernelGGL((k_wino4_in<true>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1);
   } else {
-    hipLaunchKernelGGL((k_wino4_in<false>), dim3(2 * blocks), dim3(256), 0, s, x, vimg, d_count, N, T);
+    hipLaunchKernelGGL((k_wino4_in<false>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1);
   }
 }
 
 // y == nullptr: the activations are not needed in HBM; vnext == nullptr: no next Winograd layer
 void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
-                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
+                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s, int part, int parts) {
   const int T = (N + 3) / 4;
-  const int blocks = (int)wino4_blocks(bcap, T);
+  int tb0, tb1;
+  wino4_range((int)wino4_blocks(bcap, T), part, parts, tb0, tb1);
+  if (tb1 <= tb0) return;
+  const int blocks = tb1 - tb0;
   const int per_xcd = 4 * ((blocks + 7) / 8);
   const dim3 grid(8 * per_xcd), block(256);
   wino4_check(bcap, N);
   AGZ_REQUIRE(y || vnext, AGZ_BAD_ARGUMENT, "F(4x4,3x3) GEMM: nothing to write");
-#define W4_LAUNCH(MODE_, X_) hipLaunchKernelGGL((k_wino4_gemm<MODE_, X_>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu)
+#define W4_LAUNCH(MODE_, X_) hipLaunchKernelGGL((k_wino4_gemm<MODE_, X_>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1)
 #ifdef AGZ_TIMING_EXPERIMENTS
   static const int xp = getenv("AGZ_WINO4_X") ? atoi(getenv("AGZ_WINO4_X")) : 0;
   static int traced = 0;

@@ -580,8 +580,11 @@ end
 # the f32 Winograd tower as one persistent launch (same bits as one launch per layer, include/agz.h)
 set_tower_persistent!(e::Engine, on::Bool) =
   check(e, ccall((:agz_net_set_tower_persistent, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, on ? 1 : 0))
-set_precision!(e::Engine, p::Symbol) =
-  check(e, ccall((:agz_net_set_precision, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, p === :f16 ? 1 : 0))
+# the F(4x4,3x3) tower (boards >= 13x13) as two independent layer chains on two streams (default) or one
+set_tower_streams!(e::Engine, n::Integer) =
+  check(e, ccall((:agz_net_set_tower_streams, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, n))
+set_precision!(e::Engine, p::Symbol) =      # :f32 (default, exact), :f16 (fp16 operands), :f32s (f32 as split f16 operands)
+  check(e, ccall((:agz_net_set_precision, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, p === :f16 ? 1 : p === :f32s ? 2 : 0))
 
 # ------------------------------------------------------------------ evaluate
 # evaluate(env, black_net, white_net; num_games, ro), src/neural_net.jl:103-158: both networks live

@@ -81,3 +81,33 @@ def test_sustained_mfma_rate_is_a_sane_number():
     with pytest.raises(ag.AgzError):
         eng.mfma_sustained_tflops(10)
     eng.close()
+
+
+@pytest.mark.parametrize("N,tower,B", [(19, 2, 2048), (19, 3, 1500), (17, 2, 1400), (19, 2, 1311)])
+def test_two_tower_chains_are_bit_identical_to_one(N, tower, B):
+    """The F(4x4,3x3) tower of a large batch runs as two independent layer chains -- the two halves of its tile blocks, cut at
+    a board boundary -- on two streams (agz_net_set_tower_streams, the default).  Same kernels, same rows: the outputs
+    must equal the one-chain form bit for bit, repeatedly (any difference is a missing dependency between the streams),
+    also when the batch leaves the second chain nearly empty, and the conv profile must still count every layer."""
+    rng = np.random.RandomState(N + B)
+    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    eng.init_synthetic(4)
+    feats = _feats(rng, B, N)
+    eng.set_tower_streams(1)
+    pi0, v0 = eng.forward_features(feats)
+    eng.set_tower_streams(2)
+    eng.profile_conv(True)
+    for rep in range(3):
+        pi1, v1 = eng.forward_features(feats)
+        assert (pi1 == pi0).all() and (v1 == v0).all(), (rep, np.abs(pi1 - pi0).max())
+    ms, flop, n = eng.profile_conv_read()
+    eng.profile_conv(False)
+    assert n == 3 * 2 * tower and ms > 0 and flop > 0, (ms, flop, n)
+    # a batch that fills only the first chain's range, through the same (larger) buffers
+    small = B // 3
+    eng.set_tower_streams(1)
+    spi0, sv0 = eng.forward_features(feats[:small])
+    eng.set_tower_streams(2)
+    spi1, sv1 = eng.forward_features(feats[:small])
+    assert (spi1 == spi0).all() and (sv1 == sv0).all() and (spi0 == pi0[:small]).all()
+    eng.close()
