@@ -155,7 +155,7 @@ agz_status agz_net_set_tower_persistent(agz_engine* e, int32_t on) {
 }
 agz_status agz_net_set_tower_streams(agz_engine* e, int32_t n) {
   return guard(e, [&](agz::Engine& E) {
-    AGZ_REQUIRE(n == 1 || n == 2, AGZ_BAD_ARGUMENT, "agz_net_set_tower_streams: 1 or 2");
+    AGZ_REQUIRE(n >= 1 && n <= 4, AGZ_BAD_ARGUMENT, "agz_net_set_tower_streams: 1..4");
     E.net().set_tower_streams(n);
   });
 }

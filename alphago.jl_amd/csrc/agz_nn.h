@@ -56,7 +56,7 @@ class Net {
   // the F(4x4,3x3) tower as TWO independent layer chains (the two halves of the batch's tile blocks) on two streams: the
   // hardware scheduler interleaves their workgroups, the CUs stop marching through K loops and store bursts in lockstep
   // (-5 % per forward at 19x19 / 2048 positions; outputs are bit-identical: same kernels, same rows).  1 = one chain.
-  void set_tower_streams(int n) { tower_streams_ = n >= 2 ? 2 : 1; }
+  void set_tower_streams(int n) { tower_streams_ = n < 1 ? 1 : n > kMaxTowerStreams ? kMaxTowerStreams : n; }
   int tower_streams() const { return tower_streams_; }
   bool use_wino4() const { return winograd_ && !wino_f33_only_ && precision_ == 0 && tower_ > 0 && wino4_applies(N_); }
   // the f32 Winograd tower as ONE persistent launch (k_wino_tower) instead of one launch per layer, where it applies
@@ -126,9 +126,10 @@ class Net {
   bool winograd_ = true, wino_f33_only_ = false;
   DevBuf<float> d_uwino4_;                     // F(4x4,3x3) transformed weights (agz_wino4.hip), packed when first used
   bool packed4_ = false;
+  static constexpr int kMaxTowerStreams = 4;
   int tower_streams_ = 2;
-  hipStream_t stream2_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipStream_t streamx_[kMaxTowerStreams - 1] = {nullptr, nullptr, nullptr};      // chains 1.. (chain 0 runs on stream_)
+  hipEvent_t ev_fork_ = nullptr, ev_join_[kMaxTowerStreams - 1] = {nullptr, nullptr, nullptr};
   DevBuf<float> d_uwino_s_, d_scale_s_;        // split form: weights as halves, scale x 1 / (operand scales)
   bool packed_split_ = false;
   DevBuf<float> d_uwino_, d_vimg_, d_vimg2_;   // transformed weights (stage images) / transformed activations (ping-pong)

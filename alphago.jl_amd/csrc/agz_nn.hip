@@ -741,20 +741,23 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         launch_wino4_in(a, vcur, d_count, bcap, N_, stream_, false);
         // Two chains on two streams when the batch is large enough to fill the chip twice over (>= 4 workgroup rounds
         // per chain); the chains touch disjoint rows of the same buffers.
-        const int parts = (tower_streams_ == 2 && (long)bcap * ((N_ + 3) / 4) * ((N_ + 3) / 4) >= 4 * 64 * 64 * 2) ? 2 : 1;
-        if (parts == 2 && !stream2_) {
-          AGZ_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
-          AGZ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-          AGZ_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-        }
+        // (a chain should still fill the chip a few times over: at least ~4 workgroup rounds = 256 tile blocks each)
+        const long tblocks = ((long)bcap * ((N_ + 3) / 4) * ((N_ + 3) / 4) + 63) / 64;
+        const int parts = (int)std::max<long>(1, std::min<long>(tower_streams_, tblocks / 256));
+        if (parts > 1 && !ev_fork_) AGZ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        for (int i = 0; i + 1 < parts; ++i)
+          if (!streamx_[i]) {
+            AGZ_HIP(hipStreamCreateWithFlags(&streamx_[i], hipStreamNonBlocking));
+            AGZ_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
+          }
         const bool pt = prof_on_ && prof_n_ < kProfMax;
-        if (parts == 2) {
+        if (parts > 1) {
           if (pt) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);        // (the whole tower between one event pair)
           AGZ_HIP(hipEventRecord(ev_fork_, stream_));
-          AGZ_HIP(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+          for (int i = 0; i + 1 < parts; ++i) AGZ_HIP(hipStreamWaitEvent(streamx_[i], ev_fork_, 0));
         }
         for (int part = 0; part < parts; ++part) {
-          hipStream_t st = part == 0 ? stream_ : stream2_;
+          hipStream_t st = part == 0 ? stream_ : streamx_[part - 1];
           float *pa = a, *pb = b, *vc = vcur, *vn = vnxt;
           for (int blk = 0; blk < tower_; ++blk) {
             const int l1 = 2 * blk, l2 = 2 * blk + 1;
@@ -774,9 +777,11 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
             std::swap(pa, pb);
           }
         }
-        if (parts == 2) {
-          AGZ_HIP(hipEventRecord(ev_join_, stream2_));
-          AGZ_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+        if (parts > 1) {
+          for (int i = 0; i + 1 < parts; ++i) {
+            AGZ_HIP(hipEventRecord(ev_join_[i], streamx_[i]));
+            AGZ_HIP(hipStreamWaitEvent(stream_, ev_join_[i], 0));
+          }
           if (pt) {
             (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
             prof_mult_[prof_n_] = 2 * tower_;
@@ -921,8 +926,10 @@ Net::~Net() {
   if (prof_counts_) (void)hipHostFree(prof_counts_);
   if (tower_err_) (void)hipHostFree(tower_err_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-  if (ev_join_) (void)hipEventDestroy(ev_join_);
-  if (stream2_) (void)hipStreamDestroy(stream2_);
+  for (auto e : ev_join_)
+    if (e) (void)hipEventDestroy(e);
+  for (auto st : streamx_)
+    if (st) (void)hipStreamDestroy(st);
 }
 
 void Net::profile_enable(bool on) {

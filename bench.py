@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--winograd", type=int, default=1, choices=[0, 1, 2],
                     help="agz_net_set_winograd: 1 = default (F(4x4,3x3) from 13x13 up in exact f32, else F(3x3,3x3)), "
                          "2 = F(3x3,3x3) everywhere, 0 = direct implicit GEMM")
-    ap.add_argument("--tower-streams", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--tower-streams", type=int, default=2, choices=[1, 2, 3, 4],
                     help="agz_net_set_tower_streams: the F(4x4,3x3) tower as 2 (default) or 1 layer chains")
     ap.add_argument("--tower-persistent", action="store_true",
                     help="run the f32 Winograd tower as one persistent launch (agz_net_set_tower_persistent; same bits, DESIGN.md 4f)")

@@ -83,8 +83,8 @@ def test_sustained_mfma_rate_is_a_sane_number():
     eng.close()
 
 
-@pytest.mark.parametrize("N,tower,B", [(19, 2, 2048), (19, 3, 1500), (17, 2, 1400), (19, 2, 1311)])
-def test_two_tower_chains_are_bit_identical_to_one(N, tower, B):
+@pytest.mark.parametrize("N,tower,B,chains", [(19, 2, 2048, 2), (19, 3, 1500, 2), (17, 2, 1400, 2), (19, 2, 1311, 2), (19, 2, 2700, 4)])
+def test_two_tower_chains_are_bit_identical_to_one(N, tower, B, chains):
     """The F(4x4,3x3) tower of a large batch runs as two independent layer chains -- the two halves of its tile blocks, cut at
     a board boundary -- on two streams (agz_net_set_tower_streams, the default).  Same kernels, same rows: the outputs
     must equal the one-chain form bit for bit, repeatedly (any difference is a missing dependency between the streams),
@@ -95,7 +95,7 @@ def test_two_tower_chains_are_bit_identical_to_one(N, tower, B):
     feats = _feats(rng, B, N)
     eng.set_tower_streams(1)
     pi0, v0 = eng.forward_features(feats)
-    eng.set_tower_streams(2)
+    eng.set_tower_streams(chains)
     eng.profile_conv(True)
     for rep in range(3):
         pi1, v1 = eng.forward_features(feats)
@@ -107,7 +107,7 @@ def test_two_tower_chains_are_bit_identical_to_one(N, tower, B):
     small = B // 3
     eng.set_tower_streams(1)
     spi0, sv0 = eng.forward_features(feats[:small])
-    eng.set_tower_streams(2)
+    eng.set_tower_streams(chains)
     spi1, sv1 = eng.forward_features(feats[:small])
     assert (spi1 == spi0).all() and (sv1 == sv0).all() and (spi0 == pi0[:small]).all()
     eng.close()
