@@ -11,4 +11,8 @@ done
 [ -s gpurun_out/r04prof_c4/pmc_traffic.json ] && cp gpurun_out/r04prof_c4/pmc_traffic.json profiles/r04_pmc_traffic_19x19_f32.json
 [ -s gpurun_out/r04prof_c5/pmc_traffic.json ] && cp gpurun_out/r04prof_c5/pmc_traffic.json profiles/r04_pmc_traffic_19x19_f16.json
 [ -s gpurun_out/r04prof_f16/pmc_traffic.json ] && cp gpurun_out/r04prof_f16/pmc_traffic.json profiles/r04_pmc_traffic_9x9_f16.json
+for f in bench_f32 c4_bench c4_bench_f33 c5_bench bench_f16 bench_2rank_single_device bench_8rank_single_device generation; do
+  [ -s gpurun_out/r04lines/$f.json ] && tail -1 gpurun_out/r04lines/$f.json > profiles/r04_$f.json
+done
+[ -s gpurun_out/r04lines/gpu_tests.log ] && cp gpurun_out/r04lines/gpu_tests.log profiles/r04_gpu_tests.log
 git status --short profiles | head -40
