@@ -202,7 +202,7 @@ void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, i
 // V, U -> y (if y != NULL: affine, residual, ReLU applied) and / or the NEXT layer's V (if vnext != NULL)
 void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s,
-                      int ns = kWinoStages);
+                      int ns = kWinoStages, int part = 0, int parts = 1);
 bool wino_fusable(int N);
 // the tower in one persistent launch (agz_wino.hip: k_wino_tower).  Layer table entry, device side:
 struct WinoTowerLayer {

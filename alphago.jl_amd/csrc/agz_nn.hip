@@ -831,21 +831,58 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         }
         (void)hipMemcpyAsync(tower_err_, d_tower_sched_.p + kWinoTowerErrWord, sizeof(int32_t), hipMemcpyDeviceToHost, stream_);
         if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
-      } else
-      for (int blk = 0; blk < tower_; ++blk) {     // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32
-        const int l1 = 2 * blk, l2 = 2 * blk + 1;
-        const bool last = blk + 1 == tower_;
-        timed([&] {
-          launch_wino_gemm(vcur, usrc + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, dense ? t : nullptr, vnxt,
-                           d_count, bcap, N_, 1, split, stream_);
-          if (dense) launch_wino_in(t, vnxt, d_count, bcap, N_, split, stream_, kWinoStages, true);
-        });
-        timed([&] {
-          launch_wino_gemm(vnxt, usrc + uper * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, a, b,
-                           last ? nullptr : vcur, d_count, bcap, N_, 1, split, stream_);
-          if (dense && !last) launch_wino_in(b, vcur, d_count, bcap, N_, split, stream_, kWinoStages, true);
-        });
-        std::swap(a, b);
+      } else {
+      // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32.  With whole-board tile blocks the batch's tile blocks can
+      // run as independent layer chains on several streams, like the F(4x4,3x3) tower's (above).  Measured on the 9x9
+      // headline, where the layer sits on the board's power limit: AGZ_TOWER_STREAMS_F33 (experiment knob, default 1 chain).
+      static const int chains33 = getenv("AGZ_TOWER_STREAMS_F33") ? atoi(getenv("AGZ_TOWER_STREAMS_F33")) : 1;
+      const long tblocks3 = ((long)bcap * ((N_ + 2) / 3) * ((N_ + 2) / 3) + 62) / 63;
+      const int parts = dense ? 1 : (int)std::max<long>(1, std::min<long>(std::min(chains33, (int)kMaxTowerStreams), tblocks3 / 256));
+      if (parts > 1 && !ev_fork_) AGZ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+      for (int i = 0; i + 1 < parts; ++i)
+        if (!streamx_[i]) {
+          AGZ_HIP(hipStreamCreateWithFlags(&streamx_[i], hipStreamNonBlocking));
+          AGZ_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
+        }
+      const bool pt = prof_on_ && prof_n_ < kProfMax;
+      if (parts > 1) {
+        if (pt) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+        AGZ_HIP(hipEventRecord(ev_fork_, stream_));
+        for (int i = 0; i + 1 < parts; ++i) AGZ_HIP(hipStreamWaitEvent(streamx_[i], ev_fork_, 0));
+      }
+      for (int part = 0; part < parts; ++part) {
+        hipStream_t st = part == 0 ? stream_ : streamx_[part - 1];
+        float *pa = a, *pb = b;
+        for (int blk = 0; blk < tower_; ++blk) {
+          const int l1 = 2 * blk, l2 = 2 * blk + 1;
+          const bool last = blk + 1 == tower_;
+          auto layer1 = [&] {
+            launch_wino_gemm(vcur, usrc + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, dense ? t : nullptr, vnxt,
+                             d_count, bcap, N_, 1, split, st, kWinoStages, part, parts);
+            if (dense) launch_wino_in(t, vnxt, d_count, bcap, N_, split, st, kWinoStages, true);
+          };
+          auto layer2 = [&] {
+            launch_wino_gemm(vnxt, usrc + uper * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, pa, pb,
+                             last ? nullptr : vcur, d_count, bcap, N_, 1, split, st, kWinoStages, part, parts);
+            if (dense && !last) launch_wino_in(pb, vcur, d_count, bcap, N_, split, st, kWinoStages, true);
+          };
+          if (parts == 1) { timed(layer1); timed(layer2); }
+          else { layer1(); layer2(); }
+          std::swap(pa, pb);
+        }
+      }
+      if (parts > 1) {
+        for (int i = 0; i + 1 < parts; ++i) {
+          AGZ_HIP(hipEventRecord(ev_join_[i], streamx_[i]));
+          AGZ_HIP(hipStreamWaitEvent(stream_, ev_join_[i], 0));
+        }
+        if (pt) {
+          (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
+          prof_mult_[prof_n_] = 2 * tower_;
+          prof_fwd_of_[prof_n_++] = prof_fwd_;
+        }
+      }
+      if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
       }
       }
     } else {                                         // the direct implicit GEMM (agz_net_set_winograd(0)); the stem ran above

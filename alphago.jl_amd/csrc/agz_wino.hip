@@ -32,6 +32,7 @@
 #include "agz_nn.h"
 #include "agz_glds.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -775,7 +776,7 @@ template <int MODE, int X = 0, bool SPLIT = false, int NS = WNS>
 __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu) {
+    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu, int tb0, int tb1) {
   __shared__ __attribute__((aligned(256))) float lds[3 * STAGE];
   __shared__ int ptab[WT * 9];     // element offset of output point X in y / res, or -1 (off the board / dead row)
   const long Mt = (long)(*d_count) * (T * T);
@@ -787,8 +788,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   const int bid = blockIdx.x;
   const int xcd = bid & 7, jb = bid >> 3;
   const int cb = jb & 3;
-  const int tb = xcd + 8 * (jb >> 2);
-  if ((long)tb * wino_rows_per_block(T) >= Mt) return;
+  const int tb = tb0 + xcd + 8 * (jb >> 2);      // this launch covers tile blocks [tb0, tb1) (launch_wino_gemm: part / parts)
+  if (tb >= tb1 || (long)tb * wino_rows_per_block(T) >= Mt) return;
   wino_wg<X, SPLIT, NS, false>(lds, ptab, vimg, uimg, scale, shift, res, y, vnext, Mt, N, T, relu, tb, cb, MODE, (int)threadIdx.x);
 }
 
@@ -1025,21 +1026,30 @@ void launch_wino_in(const float* x, float* vimg, const int* d_count, int bcap, i
 // y == nullptr: the activations are not needed in HBM (only their transform is); vnext == nullptr: no next
 // Winograd layer (or a board size whose tile blocks do not hold whole boards: wino_fusable(N) is false)
 void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
-                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s, int ns) {
+                      float* y, float* vnext, const int* d_count, int bcap, int N, int relu, bool split, hipStream_t s, int ns, int part,
+                      int parts) {
   const int T = (N + 2) / 3;
-  const int blocks = (int)wino_blocks(bcap, T);
+  // part / parts: the part-th of `parts` equal ranges of tile blocks.  With whole-board blocks a range's layers depend on
+  // nothing outside it, so ranges can run as independent layer chains on different streams (Net::forward)
+  const int all_blocks = (int)wino_blocks(bcap, T);
+  AGZ_REQUIRE(parts >= 1 && part >= 0 && part < parts && (parts == 1 || wino_whole_boards(T)), AGZ_BAD_ARGUMENT,
+              "tile-block range %d of %d", part, parts);
+  const int per_part = (all_blocks + parts - 1) / parts;
+  const int tb0 = std::min(all_blocks, part * per_part), tb1 = part + 1 == parts ? all_blocks : std::min(all_blocks, tb0 + per_part);
+  if (tb1 <= tb0) return;
+  const int blocks = tb1 - tb0;
   const int per_xcd = 4 * ((blocks + 7) / 8);   // see the placement comment in k_wino_gemm4
   const dim3 grid(8 * per_xcd), block(256);
-  AGZ_REQUIRE((long)(blocks + 1) * WT < (1L << 31) && (long)bcap * N * N * kC * 4 < (1L << 32), AGZ_BAD_ARGUMENT,
+  AGZ_REQUIRE((long)(all_blocks + 1) * WT < (1L << 31) && (long)bcap * N * N * kC * 4 < (1L << 32), AGZ_BAD_ARGUMENT,
               "batch of %d positions at %dx%d: tile index / activation byte offset exceeds 32 bits", bcap, N, N);
   if (ns == kWinoStemStages) {                   // the stem: its output is always wanted in HBM (block 0's residual)
     constexpr int S = kWinoStemStages;
     if (split) {
-      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, 0, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
-      else hipLaunchKernelGGL((k_wino_gemm4<1, 0, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, 0, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      else hipLaunchKernelGGL((k_wino_gemm4<1, 0, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     } else {
-      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, 0, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
-      else hipLaunchKernelGGL((k_wino_gemm4<1, 0, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, 0, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      else hipLaunchKernelGGL((k_wino_gemm4<1, 0, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     }
     return;
   }
@@ -1047,7 +1057,7 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   static const int xp = getenv("AGZ_WINO_X") ? atoi(getenv("AGZ_WINO_X")) : 0;
   static int traced = 0;
   if (getenv("AGZ_WINO_TRACE") && y && vnext && res && !split && ++traced == 3) {      // third steady-state layer launch
-    hipLaunchKernelGGL((k_wino_gemm4<3>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    hipLaunchKernelGGL((k_wino_gemm4<3>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     (void)hipStreamSynchronize(s);
     static unsigned long long host[16384][8];
     (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_trace), sizeof(host));
@@ -1060,7 +1070,7 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   if (xp && y && vnext && res && split) {
     auto kern = xp == 1 ? k_wino_gemm4<3, 1, true> : xp == 2 ? k_wino_gemm4<3, 2, true> : xp == 3 ? k_wino_gemm4<3, 3, true>
               : xp == 5 ? k_wino_gemm4<3, 5, true> : k_wino_gemm4<3, 0, true>;
-    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     return;
   }
   if (xp && y && vnext && res && !split) {
@@ -1068,25 +1078,25 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
               : xp == 4 ? k_wino_gemm4<3, 4> : xp == 5 ? k_wino_gemm4<3, 5> : xp == 6 ? k_wino_gemm4<3, 6>
               : xp == 16 ? k_wino_gemm4<3, 16> : xp == 17 ? k_wino_gemm4<3, 17> : xp == 18 ? k_wino_gemm4<3, 18> : xp == 13 ? k_wino_gemm4<3, 13> : xp == 14 ? k_wino_gemm4<3, 14> : xp == 15 ? k_wino_gemm4<3, 15> : xp == 7 ? k_wino_gemm4<3, 7> : xp == 8 ? k_wino_gemm4<3, 8> : xp == 9 ? k_wino_gemm4<3, 9> : xp == 10 ? k_wino_gemm4<3, 10>
               : xp == 11 ? k_wino_gemm4<1, 0> : xp == 12 ? k_wino_gemm4<2, 0> : k_wino_gemm4<3, 0>;
-    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, xp == 12 ? nullptr : res, y, vnext, d_count, N, T, relu);
+    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, xp == 12 ? nullptr : res, y, vnext, d_count, N, T, relu, tb0, tb1);
     return;
   }
 #endif
   if (split) {
     if (y && vnext)
-      hipLaunchKernelGGL((k_wino_gemm4<3, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+      hipLaunchKernelGGL((k_wino_gemm4<3, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     else if (vnext)
-      hipLaunchKernelGGL((k_wino_gemm4<2, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+      hipLaunchKernelGGL((k_wino_gemm4<2, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     else
-      hipLaunchKernelGGL((k_wino_gemm4<1, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+      hipLaunchKernelGGL((k_wino_gemm4<1, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     return;
   }
   if (y && vnext)
-    hipLaunchKernelGGL((k_wino_gemm4<3>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    hipLaunchKernelGGL((k_wino_gemm4<3>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
   else if (vnext)
-    hipLaunchKernelGGL((k_wino_gemm4<2>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    hipLaunchKernelGGL((k_wino_gemm4<2>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
   else
-    hipLaunchKernelGGL((k_wino_gemm4<1>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu);
+    hipLaunchKernelGGL((k_wino_gemm4<1>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
 }
 
 size_t wino_tower_sched_ints(int layers, int bcap, int N) {

@@ -214,3 +214,50 @@ def test_initialize_game_from_a_midgame_position_keeps_its_history():
         match = [a for a in cands
                  if (ag.get_feats(pos.play_move(ag.from_flat(a, env))).transpose(0, 2, 1).reshape(-1) == f).all()]
         assert len(match) == 1, "leaf features are not those of any child position with the reference's history"
+
+
+def test_node_level_surface_and_suggest_move():
+    """The names test/test_mcts.jl:2-5 and test_mcts_player.jl:3-6 import, on the host mirror's node handle (the Julia
+    wrapper binds the same entry points: tests/test_abi.py checks its ccalls): select_leaf / maybe_add_child /
+    add_virtual_loss / incorporate_results / inject_noise / child_U / child_action_score / set_N as methods of a node,
+    and suggest_move / get_position (mcts_play.jl:141-151) on the player."""
+    env = GoEnv(N)
+    probs = np.ones(env.action_space, np.float32) * 0.02
+    probs[17] = 0.4
+    player = MCTSPlayer(env, DummyNet(env, fake_priors=probs, fake_value=0.1), num_readouts=24)
+    player.initialize_game()
+    root = player.root
+    leaf = root.select_leaf()                                   # the unexpanded root is its own leaf (mcts.jl:114-118)
+    assert leaf == root and not root.is_expanded
+    leaf.incorporate_results(probs, 0.1, root)
+    assert root.is_expanded and root.N == 1
+    # child_action_score = child_Q * to_play + child_U (mcts.jl:86-92), Float64; child_U in the reference's mixed precision
+    u = root.child_U
+    assert np.allclose(root.child_action_score, root.child_Q.astype(np.float64) * root.position.to_play + u, rtol=0, atol=1e-12)
+    assert int(np.argmax(root.child_action_score)) == 17
+    child = root.maybe_add_child(17)
+    assert root.children[17] == child and child.fmove == 17 and child.position.n == 1
+    assert root.maybe_add_child(17) == child                    # idempotent (mcts.jl:141-147)
+    w0, rootw0 = root.child_W[17], root.W
+    assert w0 == np.float32(0.1)                                # child_W is seeded with the parent's value (mcts.jl:209)
+    child.add_virtual_loss(root)                                # W += position.to_play along the path, up_to included (mcts.jl:151-163)
+    assert child.losses_applied == 1 and root.losses_applied == 1
+    assert root.child_W[17] == w0 + np.float32(WHITE) and root.W == np.float32(rootw0 + BLACK) and root.child_N[17] == 0
+    child.revert_virtual_loss(root)
+    assert child.losses_applied == 0 and root.losses_applied == 0 and root.child_W[17] == w0 and root.W == rootw0
+    before = root.child_prior.copy()
+    root.inject_noise()
+    after = root.child_prior
+    assert abs(after.sum() - 1.0) < 1e-3 and (after != before).any()
+    child.set_N(5.0)
+    assert child.N == 5.0 and root.child_N[17] == 5.0
+    child.set_N(0.0)
+    with pytest.raises(AssertionError):                        # mcts.jl:190: a 10-entry probability vector is a shape error
+        child.incorporate_results(np.ones(10, np.float32), 0.0, root)
+    # suggest_move: searches until the root has num_readouts more visits, then picks (mcts_play.jl:144-151)
+    n0 = player.root.N
+    mv = player.suggest_move()
+    assert player.root.N >= n0 + 24 and player.engine.pending_vlosses(0) == 0
+    assert mv is None or (0 <= mv[0] < N and 0 <= mv[1] < N)
+    pos = player.get_position()
+    assert pos.n == 0 and pos.to_play == BLACK and (np.asarray(pos.board) == 0).all()
