@@ -53,9 +53,10 @@ class Net {
   // exact-f32 arithmetic), 2 = Winograd F(3x3,3x3) on every board size (A/B runs), 0 = the direct implicit GEMM
   void set_winograd(int mode) { winograd_ = mode != 0; wino_f33_only_ = mode == 2; }
   bool winograd() const { return winograd_; }
-  // the F(4x4,3x3) tower as TWO independent layer chains (the two halves of the batch's tile blocks) on two streams: the
-  // hardware scheduler interleaves their workgroups, the CUs stop marching through K loops and store bursts in lockstep
-  // (-5 % per forward at 19x19 / 2048 positions; outputs are bit-identical: same kernels, same rows).  1 = one chain.
+  // The Winograd tower of a large batch as n independent layer chains (ranges of its tile blocks, cut at board boundaries)
+  // on n streams: the hardware scheduler interleaves their workgroups, the CUs stop marching through K loops and store
+  // bursts in lockstep (-5 % per forward at 19x19 / 2048 positions, -1.6 % per step at 9x9 / 8192; outputs are
+  // bit-identical: same kernels, same rows).  Applies to whole-board F(3x3,3x3) blocks and to the F(4x4,3x3) tower.
   void set_tower_streams(int n) { tower_streams_ = n < 1 ? 1 : n > kMaxTowerStreams ? kMaxTowerStreams : n; }
   int tower_streams() const { return tower_streams_; }
   bool use_wino4() const { return winograd_ && !wino_f33_only_ && precision_ == 0 && tower_ > 0 && wino4_applies(N_); }
@@ -220,7 +221,7 @@ float wino_split_descale();
 
 // Winograd F(4x4,3x3) tower convolution for boards of 13x13 and larger (agz_wino4.hip): 36 planes in four passes over
 // the input channels, each folded into the inverse transform when its K loop ends; tiles of 4x4 outputs, T = ceil(N / 4)
-constexpr int kWino4Stages = 96;             // K-loop stages of a layer: 32 + 32 (12 planes x 8 cin) + 16 + 16 (6 planes x 16 cin)
+constexpr int kWino4Stages = 96;             // K-loop stages of a layer: six passes (transform rows) x 16 stages of 6 planes x 16 cin
 bool wino4_applies(int N);                   // N >= 13: fewer multiplies per output point than F(3x3,3x3)
 bool wino4_whole_boards(int N);              // tile blocks hold whole boards (N = 13..16); else dense blocks + fix-up transform
 void wino4_pack_weights(const ConvHost& c, float* out);

@@ -18,21 +18,19 @@
 //
 // The problem this kernel is built around: a workgroup tile of 64 tiles x 64 couts (the one that gives 16 flop per
 // LDS-DMA byte, agz_wino.hip) needs 36 planes x 16 accumulator registers = 576 per lane with one wave per SIMD -- more
-// than the 512 a lane owns.  So the 36 planes are multiplied in four PASSES over the input channels, and each pass's
-// planes are folded into the inverse transform as soon as its K loop ends.  With M[i][j] the plane of transform row i
-// and column j,  Y = A^T M A = sum_i A^T[:, i] (x) (A^T M[i][:]) :
-//     pass A: rows 1, 2  (12 planes)   t_i = A^T M[i][:]  (four 16-register tuples per row);  S = t1 + t2, D = t1 - t2
-//     pass B: rows 3, 4  (12 planes)   s = t3 + t4, d = t3 - t4;  Y0 = S + s, Y1 = D + 2d, Y2 = S + 4s, Y3 = D + 8d
-//     pass C: row 0      ( 6 planes)   Y0 += t0
-//     pass D: row 5      ( 6 planes)   Y3 += t5
-// Live registers: 192 accumulators (pass A), 192 + 128 (B), 96 + 256 (C, D): the last two passes, where the 16 output
-// tuples are complete but for one term, run with the fewest accumulators.  Every byte and every MFMA of the one-pass form
-// is kept: a pass moves only its own planes of V and U.
+// than the 512 a lane owns.  So the 36 planes are multiplied in SIX PASSES over the input channels, one per transform
+// row i, and each pass is folded into the inverse transform as soon as its K loop ends.  With M[i][j] the plane of
+// transform row i and column j,  Y = A^T M A = sum_i A^T[:, i] (x) (A^T M[i][:]):  after pass i the six accumulator
+// tuples become t = A^T M[i][:] (four values per element) and Y[i'][:] += A^T[i'][i] t.  Live registers: 96 accumulators
+// + the 256 of the 16 running outputs -- nothing of either ever in scratch -- and ONE K-loop body and ONE fold (the row's
+// weights are run-time scalars) in 24 KB of code.  Every byte and every MFMA of the one-pass form is kept: a pass moves
+// only its own planes of V and U.  (History -- four passes with paired rows, 65 KB of code, tuples in scratch -- and what
+// each step measured: DESIGN.md 4g.)
 //
-// Stage = 24 UNITS; a unit = one plane x 4 input channels = 64 rows x 16 B of V and of U (1 KB each), two MFMAs per wave.
-// Passes A, B: 12 planes x 2 channel groups per stage (32 stages each); passes C, D: 6 planes x 4 groups (16 stages each):
-// 96 stages of 48 KB, triple-buffered in LDS and filled by LDS-DMA exactly like agz_wino.hip's, 12 pieces per wave and stage.
-// The stage sequence is one flat list in HBM ([pass][stage][unit]), so the DMA stream runs across pass boundaries.
+// Stage = 24 UNITS; a unit = one plane x 4 input channels = 64 rows x 16 B of V and of U (1 KB each), two MFMAs per wave;
+// a stage = 6 planes x 4 channel groups = 48 KB, 16 stages per pass, 96 per layer, triple-buffered in LDS and filled by
+// LDS-DMA exactly like agz_wino.hip's, 12 pieces per wave and stage.  The stage sequence is one flat list in HBM
+// ([pass][stage][unit]), so the DMA stream runs across pass boundaries.
 //
 // Accumulators are TRANSPOSED (D = U^T-rows x V-rows: lane = tile row, register = cout): a lane holds, per output point,
 // four consecutive couts in a register quad, so the epilogue's image pass moves 16-byte units, and the 64 couts split
@@ -42,7 +40,7 @@
 // Epilogue per half: residual half-tile -> image by LDS-DMA; BatchNorm affine in registers; image = ReLU(image + value);
 // image -> y; the NEXT layer's input transform V = B^T d B (6x6 patches from the image, lane = tile row, 1 KB contiguous
 // stores) for every tile whose patch lies in this tile block (whole-board blocks for N = 13..16: 16 tiles per board, 4
-// boards per block; dense blocks above, where k_wino4_in<FIXUP> does the block ends -- same split as agz_wino.hip).
+// boards per block; five boards per block pair above, where k_wino4_in<FIXUP> does the ends of the one board a pair cuts).
 #include "agz_nn.h"
 #include "agz_glds.h"
 
@@ -66,7 +64,7 @@ constexpr int W4UNITS = 24;                   // units per stage
 constexpr int W4UNIT = W4T * 4;               // floats of a unit image (64 rows x 4 channels): 1 KB
 constexpr int W4HALF = W4UNITS * W4UNIT;      // one operand's part of a stage: 6144 floats = 24 KB
 constexpr int W4STAGE = 2 * W4HALF;           // 48 KB
-constexpr int W4NST = kWino4Stages;           // 96 stages: 32 (rows 1,2) + 32 (rows 3,4) + 16 (row 0) + 16 (row 5)
+constexpr int W4NST = kWino4Stages;           // 96 stages: six passes (transform rows) of 16
 constexpr int W4BLOCK = W4NST * W4HALF;       // floats of V per tile block / of U per cout block: 589,824 (2.25 MB)
 constexpr int W4CP = 32;                      // couts per epilogue half
 constexpr int W4IMG = 16 * W4T * W4CP;        // floats of the half image: 128 KB

@@ -140,10 +140,11 @@ agz_status agz_net_set_winograd(agz_engine* e, int32_t on);
  * 3.7 % fewer cycles (no partly filled last workgroup round per layer) and, on a power-limited MI355X, runs at a
  * clock 4 % lower: the same wall time. */
 agz_status agz_net_set_tower_persistent(agz_engine* e, int32_t on);
-/* the F(4x4,3x3) tower (boards of 13x13 and larger, exact f32) as 2 (default) or 1 independent layer chains: with 2, the two
- * halves of a large batch's tile blocks run their layers on two HIP streams and the hardware interleaves their workgroups
- * (-5 % per forward at 19x19 / 2048 positions: the CUs stop moving through K loops and store bursts in lockstep).  Same
- * kernels, same rows: outputs are bit-identical either way. */
+/* the Winograd tower of a large batch as n = 1..4 independent layer chains (default 2): ranges of the batch's tile blocks, cut
+ * at board boundaries, run their layers on n HIP streams and the hardware interleaves their workgroups (-5 % per forward
+ * at 19x19 / 2048 positions, -1.6 % per step at 9x9 / 8192: the CUs stop moving through K loops and store bursts in
+ * lockstep).  Same kernels, same rows: outputs are bit-identical for every n (tests/test_gpu_tower.py).  Small batches
+ * (fewer than 256 tile blocks per chain) run as one chain. */
 agz_status agz_net_set_tower_streams(agz_engine* e, int32_t n);
 /* tower arithmetic of the network selected by agz_net_select.  AGZ_PRECISION_F32 (default): exact
  * f32 end to end -- the parity target of BASELINE.json's metric.  AGZ_PRECISION_F16: the "fp16 MFMA

@@ -111,3 +111,26 @@ def test_two_tower_chains_are_bit_identical_to_one(N, tower, B, chains):
     spi1, sv1 = eng.forward_features(feats[:small])
     assert (spi1 == spi0).all() and (sv1 == sv0).all() and (spi0 == pi0[:small]).all()
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+def test_tower_chains_9x9_are_bit_identical(precision):
+    """the same for the F(3x3,3x3) tower with whole-board tile blocks (the 9x9 headline: 8192 positions, 1171 tile blocks):
+    1, 2 and 4 chains, per-layer launches and the persistent launch all give the same bits"""
+    N, tower, B = 9, 4, 8192
+    rng = np.random.RandomState(9)
+    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+    eng.init_synthetic(6)
+    eng.set_precision(precision)
+    feats = _feats(rng, B, N)
+    eng.set_tower_streams(1)
+    pi0, v0 = eng.forward_features(feats)
+    for chains in (2, 4, 3):
+        eng.set_tower_streams(chains)
+        for rep in range(2):
+            pi1, v1 = eng.forward_features(feats)
+            assert (pi1 == pi0).all() and (v1 == v0).all(), (chains, rep, np.abs(pi1 - pi0).max())
+    eng.set_tower_persistent(True)
+    pi2, v2 = eng.forward_features(feats)
+    assert (pi2 == pi0).all() and (v2 == v0).all()
+    eng.close()

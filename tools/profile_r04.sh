@@ -18,7 +18,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench
 find $O/stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 for C in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   D=$O/pmc_$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python bench.py --steps $PSTEPS --warmup 1 $COMMON "$@" > $D.log 2>&1
+  # (counter passes with ONE tower chain: with two, the halves of a layer are two overlapping dispatches and per-dispatch
+  # counters / per-layer byte counts stop meaning "a layer"; the bytes and the MFMA cycles of a layer do not depend on it)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python bench.py --steps $PSTEPS --warmup 1 $COMMON --tower-streams 1 "$@" > $D.log 2>&1
 done
 python tools/pmc_traffic.py $((GAMES * 8)) $BOARD $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $O/pmc_traffic.json 2> $O/pmc_traffic.err
 python tools/pmc_mfma.py "$O/pmc_GRBM_GUI_ACTIVE_SQ_BUSY_CYCLES_SQ_VALU_M" $O/pmc_SQ_LDS_BANK_CONFLICT_SQ_LDS_IDX_ACTIVE > $O/pmc_mfma_lds.csv 2> $O/pmc_mfma.err
