@@ -252,8 +252,9 @@ class NodeView:
 
     @property
     def child_U(self):                        # mcts.jl:91-92: c_puct (Float64) x Float32 sqrt x prior / (1 + N)
-        c = float(self._p.engine.cfg.c_puct)
-        return c * np.sqrt(np.float32(1) + np.float32(self.N)) * self.child_prior / (np.float32(1) + self.child_N)
+        # Julia evaluates left to right: Float64 c_puct x the Float32 square root, then Float64 throughout
+        scale = np.float64(self._p.engine.cfg.c_puct) * np.float64(np.sqrt(np.float32(1) + np.float32(self.N)))
+        return scale * self.child_prior.astype(np.float64) / (np.float32(1) + self.child_N).astype(np.float64)
 
     def __eq__(self, other):
         return isinstance(other, NodeView) and other._p is self._p and other.id == self.id

@@ -224,6 +224,7 @@ def test_node_level_surface_and_suggest_move():
     env = GoEnv(N)
     probs = np.ones(env.action_space, np.float32) * 0.02
     probs[17] = 0.4
+    probs /= probs.sum()
     player = MCTSPlayer(env, DummyNet(env, fake_priors=probs, fake_value=0.1), num_readouts=24)
     player.initialize_game()
     root = player.root
@@ -244,7 +245,10 @@ def test_node_level_surface_and_suggest_move():
     assert child.losses_applied == 1 and root.losses_applied == 1
     assert root.child_W[17] == w0 + np.float32(WHITE) and root.W == np.float32(rootw0 + BLACK) and root.child_N[17] == 0
     child.revert_virtual_loss(root)
-    assert child.losses_applied == 0 and root.losses_applied == 0 and root.child_W[17] == w0 and root.W == rootw0
+    # (Float32, as the reference: (0.1 - 1) + 1 is 0.100000024)
+    assert child.losses_applied == 0 and root.losses_applied == 0
+    assert root.child_W[17] == (w0 + np.float32(WHITE)) - np.float32(WHITE)
+    assert root.W == np.float32(np.float32(rootw0 + BLACK) - np.float32(BLACK))
     before = root.child_prior.copy()
     root.inject_noise()
     after = root.child_prior
