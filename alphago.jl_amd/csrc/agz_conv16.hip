@@ -131,25 +131,31 @@ __device__ __forceinline__ void static_for(F&& f) {
 // RES: 0 = no residual, 1 = half, 2 = f32 (first block's skip); OUTF: the output is f32 (last layer), else half.
 // DBG (timing variants, -DAGZ_TIMING_EXPERIMENTS, wrong results): bit mask of what is compiled out -- 1 epilogue,
 // 2 weight loads, 4 LDS operand reads, 8 slab DMA, 16 MFMA, 32 result stores; 64 = the stores go to 64 fixed (L2-resident)
-// regions; 128 = non-temporal result stores.
+// regions; 128 = non-temporal result stores; 256 = streaming weight loads; 512 = the weight stream as LDS-DMA (into LDS, unused).
 // RB: row blocks of 32 per tile -- 7 (one workgroup per CU, results leave through the LDS image) or 4 (two workgroups
 // per CU, direct epilogue)
-template <int DBG, int RES, bool OUTF, int RB>
+// WL: the weight fragments reach the wave through a wave-private LDS ring filled by LDS-DMA (and the results leave through
+// the direct epilogue) instead of global_load -> registers + the trickled result image: see "Round 4" below.
+template <int DBG, int RES, bool OUTF, int RB, bool WL>
 __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const void* __restrict__ res, void* __restrict__ y,
                                                          const int* __restrict__ d_count, int N, int relu) {
   constexpr bool RESF = RES == 2;
-  constexpr bool TRICKLE = RB == W2_RB_PRODUCT && !RESF && !OUTF;
+  constexpr bool TRICKLE = !WL && RB == W2_RB_PRODUCT && !RESF && !OUTF && !(DBG & 1024);      // (1024: timing variant, direct epilogue)
   constexpr int W2_RB = RB, W2_HM = 32 * RB;
   constexpr int W2_SLABCH = ((W2_HM + 2 * 20) * 4 + 63) / 64, NPJ = (W2_SLABCH + 3) / 4;
   constexpr int W2_SLAB = W2_SLABCH * 512, W2_SLABS = W2_SLAB + 32;
   constexpr int W2_OFF_SC = 2 * W2_SLABS, W2_OFF_OUT = W2_OFF_SC + 1024;
   constexpr int TINB = RES == 0 ? 0 : (RESF ? 32 * 272 : 32 * 144), TOUTB = OUTF ? 32 * 272 : 32 * 144;   // direct epilogue tiles
   constexpr int W2_OUTB = TRICKLE ? 4 * RB * 4096 : 4 * (TINB + TOUTB);
-  constexpr int W2_SMEM = W2_OFF_OUT + W2_OUTB / 2;
-  constexpr int W2_D = RB <= 4 ? 5 : 17, W2_RING = W2_D + 1;
-  static_assert(W2_OFF_OUT % 64 == 0 && 18 % W2_RING == 0, "layout");
+  // WL: a ring of WD k-steps of this wave's two fragments (2 KB per k-step) in LDS; W2_D = how far ahead the fetch runs
+  constexpr int WD = 6;
+  constexpr int W2_OFF_W = (W2_OFF_OUT + W2_OUTB / 2 + 63) / 64 * 64;
+  constexpr int W2_SMEM = WL ? W2_OFF_W + 4 * WD * 1024 : W2_OFF_OUT + W2_OUTB / 2;
+  constexpr int W2_D = WL ? WD - 1 : (RB <= 4 ? 5 : 17), W2_RING = WL ? 2 : W2_D + 1;
+  static_assert(W2_OFF_OUT % 64 == 0 && 18 % W2_RING == 0 && 18 % WD == 0 && W2_KS % WD == 0, "layout");
+  static_assert(W2_SMEM * 2 <= 160 * 1024, "LDS");
   // direct epilogue tiles [32 rows][64 couts]: row stride / 16-byte pieces per row / pieces per lane, per element type
   constexpr int RSB = RESF ? 272 : 144, RPR = RESF ? 16 : 8, RNP = RESF ? 8 : 4;
   constexpr int OSB = OUTF ? 272 : 144, OPR = OUTF ? 16 : 8, ONP = OUTF ? 8 : 4;
@@ -227,13 +233,27 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   const char* wfw = reinterpret_cast<const char*>(wf) + wave * 2048;
   auto load_b = [&](int slot, const char* wbase, int kk) __attribute__((always_inline)) {   // this wave's two fragments of k-step kk
     const char* p = wbase + (size_t)kk * 8192;
-    if (DBG & 256) {      // (timing variant: streaming weight loads)
+    if (WL) {             // `slot` = ring slot kk % WD: 1 KB per fragment, lane * 16 within it
+      const unsigned dst = s0 + (unsigned)(W2_OFF_W + (wave * WD + slot) * 1024) * 2u;
+      glds16hs(p, wlane, dst);
+      glds16hs(p + 1024, wlane, dst + 1024u);
+    } else if (DBG & 512) {      // (timing variant: the weight stream as LDS-DMA into a corner of the result image -- results WRONG)
+      glds16hs(p, wlane, s0 + (unsigned)(W2_OFF_OUT * 2 + wave * 2048));
+      glds16hs(p + 1024, wlane, s0 + (unsigned)(W2_OFF_OUT * 2 + wave * 2048 + 1024));
+    } else if (DBG & 256) {      // (timing variant: streaming weight loads)
       Bf[slot][0] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(p + wlane));
       Bf[slot][1] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(p + 1024 + wlane));
     } else {
       Bf[slot][0] = *reinterpret_cast<const h8*>(p + wlane);
       Bf[slot][1] = *reinterpret_cast<const h8*>(p + 1024 + wlane);
     }
+  };
+
+  // WL: this wave's fragments of a k-step from its ring slot into the register pair of that k-step's parity
+  auto read_b = [&](int par, int slot) __attribute__((always_inline)) {
+    const char* q = sm + (W2_OFF_W + (wave * WD + slot) * 1024) * 2 + wlane;
+    Bf[par][0] = *reinterpret_cast<const h8*>(q);
+    Bf[par][1] = *reinterpret_cast<const h8*>(q + 1024);
   };
 
   // Result image of the workgroup: [pass 7][32 rows][512 B], a row's thirty-two 16-byte pieces swizzled by the row
@@ -263,12 +283,21 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
 #pragma unroll
   for (int j = 0; j < NPJ; ++j) dma_a(0, 0, j);
 #pragma unroll
-  for (int k = 0; k < W2_D; ++k) load_b(k, wfw, k);
+  for (int k = 0; k < W2_D; ++k) load_b(WL ? k % WD : k, wfw, k);
+  if (DBG & (2 | 512)) {      // (timing variants without weight loads into registers: operands that toggle like real ones)
+#pragma unroll
+    for (int sl = 0; sl < W2_RING; ++sl)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Bf[sl][cb][k] = (_Float16)(0.01f * (float)((lane * 7 + sl * 3 + cb * 5 + k) % 37) - 0.18f);
+  }
   tile_masks(m0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   tap_addr(0, 0);
   static_for<0, W2_RB>([&](auto ic) __attribute__((always_inline)) { read_a(0, decltype(ic)::value); });
+  if (WL && !(DBG & 2)) read_b(0, 0);
   // (the first tile has no predecessor: it sends its own rows' stale image ahead of the real one, same wave, same
   // addresses, in order -- cheaper than a branch around every piece)
   yprev = reinterpret_cast<char*>(y) + (size_t)m0 * (kC * 2);
@@ -323,7 +352,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
     for (int rbk = 0; rbk < W2_RB; ++rbk) asm volatile("" : "+v"(vm[rbk]));
     static_for<0, 18>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      constexpr int slot = i % W2_RING;
+      constexpr int slot = WL ? (i & 1) : i % W2_RING;
       constexpr int nks = (i + 1) & 1;
       if (nks == 0) {                                     // the k-step being prefetched opens a new tap
         if (i < 17) tap_addr(sbuf, (i + 1) >> 1);
@@ -347,7 +376,13 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
         }
         __builtin_amdgcn_sched_barrier(0);
         if (cb == 1 && (i < 17 || !last) && !(DBG & 4)) read_a(nks, rbk);
-        if (mi == 2 && !(DBG & 2)) load_b((i + W2_D) % W2_RING, wb, kn);
+        if (mi == 2 && !(DBG & 2)) load_b(WL ? (i + W2_D) % WD : (i + W2_D) % W2_RING, wb, kn);
+        if (WL && mi == 8 && !(DBG & 2)) {
+          // k-step i + 1's fragments: fetched WD - 2 k-steps ago; the 2 (WD - 2) pieces issued since may be in flight
+          // (anything else issued since -- slab pieces, residual loads -- only makes this wait a little longer)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WD - 2)) : "memory");
+          read_b((i + 1) & 1, (i + 1) % WD);
+        }
         // the next chunk's slab (the next tile's first, in the last chunk) goes out in k-steps 0 and 1
         // (after the last tile the spare buffer just receives the first slab once more: no branch in the loop)
         if (!(DBG & 8)) {
@@ -370,7 +405,8 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
       }
       if (i == 16) {
         // the slab pieces issued in k-steps 0 and 1 are older than the 2 W2_D weight fragments that may be in flight
-        if (W2_D == 17) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+        if (WL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WD - 1)) : "memory");
+        else if (W2_D == 17) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         __syncthreads();
       }
@@ -512,6 +548,15 @@ void launch_f32_to_f16(const float* x, uint16_t* y, const int* d_count, int bcap
   hipLaunchKernelGGL(k_f32_to_f16, dim3(grid), dim3(256), 0, s, x, (_Float16*)y, d_count, (long)N * N * kC);
 }
 
+// Round 4: the WL form (weight fragments through a wave-private LDS ring filled by LDS-DMA, six k-steps deep, results
+// through the direct epilogue; -DAGZ_C16_WL=true) was built because two timing variants (512 / 1536: the weight stream
+// as LDS-DMA into unused LDS) ran at 1.08-1.11 ms where the product takes 1.39.  Every fp16 parity test is green with it
+// -- and it takes 1.385 ms: the variants' MFMAs multiplied by a B operand that never changed, and the matrix pipe's
+// power follows its operands' toggling; with real weights in the registers the board is back on its 1305 W limit
+// whichever way they arrive.  Kept as a compile-time option, not the product.
+#ifndef AGZ_C16_WL
+#define AGZ_C16_WL false
+#endif
 void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale, const float* shift, const void* res,
                        int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
   const long rows = (long)bcap * N * N;
@@ -521,7 +566,7 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   const int rk = !res ? 0 : (res_f32 ? 2 : 1);
   const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
 #define AGZ_C16_W2(D, R, OF, RB, G) \
-  hipLaunchKernelGGL((k_conv3x3_f16_w2<D, R, OF, RB>), dim3(G), dim3(256), 0, s, xh, wi, scale, shift, res, y, d_count, N, relu)
+  hipLaunchKernelGGL((k_conv3x3_f16_w2<D, R, OF, RB, AGZ_C16_WL>), dim3(G), dim3(256), 0, s, xh, wi, scale, shift, res, y, d_count, N, relu)
 #define AGZ_C16_W2D(D, RB, G)                          \
   do {                                                 \
     if (out_f32) {                                     \
@@ -561,6 +606,10 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
     case 64: AGZ_C16_W2D(64, W2_RB_PRODUCT, grid7); return;
     case 128: AGZ_C16_W2D(128, W2_RB_PRODUCT, grid7); return;
     case 256: AGZ_C16_W2D(256, W2_RB_PRODUCT, grid7); return;
+    case 512: AGZ_C16_W2D(512, W2_RB_PRODUCT, grid7); return;
+    case 1024: AGZ_C16_W2D(1024, W2_RB_PRODUCT, grid7); return;
+    case 1536: AGZ_C16_W2D(1536, W2_RB_PRODUCT, grid7); return;
+    case 544: AGZ_C16_W2D(544, W2_RB_PRODUCT, grid7); return;
     case 34: AGZ_C16_W2D(34, W2_RB_PRODUCT, grid7); return;
     case 2: AGZ_C16_W2D(2, W2_RB_PRODUCT, grid7); return;
     default: break;
