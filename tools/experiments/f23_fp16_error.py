@@ -8,7 +8,8 @@ at the points where such a kernel would round:
   f23      F(2x2,3x3): activations stored half; V = B^T d B formed in f32/f64 from them and ROUNDED TO HALF (the MFMA
            operand); U = G k G^T formed in float64 and rounded to half; M = sum_cin U.V exact; Y = A^T M A; BatchNorm,
            residual, ReLU as in the direct form; result stored half
-  f23s     the same with U pre-scaled per plane so that its entries use the half range (a free win on the weight side)
+  f23s     the same with U and V pre-scaled per plane by powers of two so that their entries use the half range
+  f43(s)   F(4x4,3x3) with half operands the same way (the transform agz_wino4.hip runs in f32): 3.6x fewer multiplies
 
 Network: the synthetic network of tests/test_gpu_configs.py (glorot weights, BatchNorm statistics randomised), B positions
 of random stones.  Prints max |d pi|, |d v| against the exact float64 network.  Needs oracle/liboracle.so (tests/orc.py)."""
@@ -31,6 +32,12 @@ h16 = lambda t: t.to(torch.float16).to(dt)      # round to IEEE half, keep worki
 BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=dt)
 G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=dt)
 AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=dt)
+# F(4x4,3x3), points {0, +-1, +-2, inf} (agz_wino4.hip)
+BT4 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                    [0, 4, 0, -5, 0, 1]], dtype=dt)
+G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                   [0, 0, 1]], dtype=dt)
+AT4 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=dt)
 
 
 def params(net, l, cin, cout, k):
@@ -53,20 +60,29 @@ def conv_direct(x, w):
 def conv_f23(x, w, mode):
     """x [B, C, 19, 19] (already half-rounded where the mode says so), w [O, C, 3, 3] correlation kernel"""
     Bn, C, H, W = x.shape
-    T = (H + 1) // 2
-    xp = torch.nn.functional.pad(x, (1, 2 * T - W + 1, 1, 2 * T - H + 1))
-    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                      # [B, C, T, T, 4, 4]
-    V = torch.einsum("iu,bctsuv,jv->bctsij", BT, d, BT)
-    U = torch.einsum("ia,ocab,jb->ocij", G, w, G)               # [O, C, 4, 4]
-    if mode == "f23s":
+    big = mode.startswith("f43")
+    m, a_ = (4, 6) if big else (2, 4)
+    bt, g, at = (BT4, G4, AT4) if big else (BT, G, AT)
+    T = (H + m - 1) // m
+    xp = torch.nn.functional.pad(x, (1, m * T - W + 1, 1, m * T - H + 1))
+    d = xp.unfold(2, a_, m).unfold(3, a_, m)                    # [B, C, T, T, a, a]
+    V = torch.einsum("iu,bctsuv,jv->bctsij", bt, d, bt)
+    U = torch.einsum("ia,ocab,jb->ocij", g, w, g)               # [O, C, a, a]
+    if mode.endswith("s"):
         s = U.abs().amax(dim=(0, 1), keepdim=True)               # per-plane scale to use the half range
         s = 2.0 ** torch.floor(torch.log2(1.0 / s))
     else:
-        s = torch.ones(1, 1, 4, 4, dtype=dt)
-    Uh, Vh = h16(U * s), h16(V)
-    M = torch.einsum("ocij,bctsij->botsij", Uh, Vh) / s.reshape(1, 1, 1, 1, 4, 4)
-    Y = torch.einsum("pi,botsij,qj->botspq", AT, M, AT)          # [B, O, T, T, 2, 2]
-    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(Bn, -1, 2 * T, 2 * T)
+        s = torch.ones(1, 1, a_, a_, dtype=dt)
+    if mode.endswith("s"):
+        # ... and V per plane too: a power of two that brings the plane's largest entry of this batch near 1 (a kernel
+        # would use a fixed per-plane constant; the transform's row sums bound it)
+        sv = 2.0 ** torch.floor(torch.log2(1.0 / V.abs().amax(dim=(0, 1, 2, 3), keepdim=True).clamp_min(1e-30)))
+    else:
+        sv = torch.ones(1, 1, 1, 1, a_, a_, dtype=dt)
+    Uh, Vh = h16(U * s), h16(V * sv)
+    M = torch.einsum("ocij,bctsij->botsij", Uh, Vh) / (s.reshape(1, 1, 1, 1, a_, a_) * sv)
+    Y = torch.einsum("pi,botsij,qj->botspq", at, M, at)          # [B, O, T, T, m, m]
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(Bn, -1, m * T, m * T)
     return y[:, :, :H, :W]
 
 
@@ -81,13 +97,13 @@ def forward(net, x, mode):
     for blk in range(TOWER):
         w1, sc1, sh1 = params(net, 1 + 2 * blk, 256, 256, 3)
         w2, sc2, sh2 = params(net, 2 + 2 * blk, 256, 256, 3)
-        if mode in ("f23", "f23s"):
+        if mode in ("f23", "f23s", "f43", "f43s"):
             c1 = conv_f23(a, w1, mode)
         else:
             c1 = conv_direct(a, h16(w1) if half else w1)
         t = torch.relu(c1 * sc1[None, :, None, None] + sh1[None, :, None, None])
         t = h16(t) if half else t
-        if mode in ("f23", "f23s"):
+        if mode in ("f23", "f23s", "f43", "f43s"):
             c2 = conv_f23(t, w2, mode)
         else:
             c2 = conv_direct(t, h16(w2) if half else w2)
@@ -136,7 +152,7 @@ def main():
         h16 = keep
         print(f"F(2x2,3x3) identity without roundings: max |diff| {alg:.2e}")
         print(f"19x19, tower {TOWER}, {B} positions; pi max {pi0.max():.3e}, |v| max {np.abs(v0).max():.3f}")
-        for mode in ("direct", "f23", "f23s"):
+        for mode in ("direct", "f23", "f23s", "f43", "f43s"):
             pi, v = forward(net, x, mode)
             print(f"{mode:7s} vs exact f64: max |d pi| {np.abs(pi - pi0).max():.2e}   max |d v| {np.abs(v - v0).max():.2e}")
     L.or_net_free(net)
