@@ -265,3 +265,27 @@ def test_node_level_surface_and_suggest_move():
     assert mv is None or (0 <= mv[0] < N and 0 <= mv[1] < N)
     pos = player.get_position()
     assert pos.n == 0 and pos.to_play == BLACK and (np.asarray(pos.board) == 0).all()
+
+
+def test_softpick_assertion_matches_the_reference_failure():
+    """mcts_play.jl:63-67 on the device: visits on the pass only (or none) below the temperature threshold fail the
+    soft pick's assertion -- AGZ_ASSERT_SOFTPICK through the C ABI, AssertionError in the host mirror (the reference's
+    @assert) -- and one visited board move makes it succeed; the same cases as tests/test_oracle_player.py."""
+    env = GoEnv(N)
+    player = MCTSPlayer(env, DummyNet(env), num_readouts=8)
+    player.initialize_game()
+    player.tree_search()
+    e, root = player.engine, player.engine.tree_root(0)
+    cn = np.zeros(env.action_space, np.float32)
+    e.node_set_floats(0, root, ag._lib.F_CHILD_N, cn)
+    assert e.pick_move(0)[0] == ag._lib.ASSERT_SOFTPICK
+    cn[-1] = 3
+    e.node_set_floats(0, root, ag._lib.F_CHILD_N, cn)
+    assert e.pick_move(0)[0] == ag._lib.ASSERT_SOFTPICK
+    with pytest.raises(AssertionError):
+        player.pick_move()
+    cn[17] = 1
+    e.node_set_floats(0, root, ag._lib.F_CHILD_N, cn)
+    st, a = e.pick_move(0)
+    assert st == ag._lib.OK and a == 17
+    assert player.pick_move() == ag.from_flat(17, env)

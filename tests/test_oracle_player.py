@@ -293,3 +293,26 @@ def test_selfplay_5x5_plumbing():
         L.or_player_free(p2)
     assert total > 4
     L.or_net_free(net)
+
+
+def test_softpick_assertion_fails_when_no_board_move_was_visited():
+    """mcts_play.jl:63-67: below the temperature threshold the move is drawn from the visit counts of the BOARD moves
+    (`cdf /= cdf[end - 1]`: "prevents passing via softpick") and `@assert child_N[fcoord] != 0`.  With visits on the pass
+    only -- or none at all -- the normaliser is 0, the cdf is NaN (or 0/0), searchsortedfirst runs off the end and the
+    assertion fails: the oracle reports OR_ASSERT_SOFTPICK (the reference would throw; its self-play loop would die, ours
+    plays a pass: DESIGN.md 8, deviations).  A visited board move makes it succeed again."""
+    net = DummyNet(A)
+    p = new_player(net)
+    L.or_player_initialize_game(p, None)
+    L.or_player_tree_search(p, 8)                       # expands the root; n = 0 < tau_threshold
+    assert L.or_player_tau_threshold(p) > 0
+    root = L.or_player_root(p)
+    cn = orc.node_arr(L.or_node_child_N(root), A)
+    a = C.c_int(-7)
+    cn[:] = 0
+    assert L.or_player_pick_move(p, C.byref(a)) == orc.ASSERT_SOFTPICK
+    cn[PASS] = 3
+    assert L.or_player_pick_move(p, C.byref(a)) == orc.ASSERT_SOFTPICK
+    cn[17] = 1
+    assert L.or_player_pick_move(p, C.byref(a)) == orc.OK and a.value == 17      # the only board move with visits
+    L.or_player_free(p)
