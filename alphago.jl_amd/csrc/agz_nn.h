@@ -219,7 +219,7 @@ constexpr int kWinoTowerErrWord = 8;         // int offset of the scheduler's er
 void wino_pack_weights_split(const ConvHost& c, float* out, int ns = kWinoStages);
 float wino_split_descale();
 
-// Winograd F(4x4,3x3) tower convolution for boards of 13x13 and larger (agz_wino4.hip): 36 planes in four passes over
+// Winograd F(4x4,3x3) tower convolution for boards of 13x13 and larger (agz_wino4.hip): 36 planes in six one-row passes over
 // the input channels, each folded into the inverse transform when its K loop ends; tiles of 4x4 outputs, T = ceil(N / 4)
 constexpr int kWino4Stages = 96;             // K-loop stages of a layer: six passes (transform rows) x 16 stages of 6 planes x 16 cin
 bool wino4_applies(int N);                   // N >= 13: fewer multiplies per output point than F(3x3,3x3)

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   }
 }
 
-// ------------------------------------------------------------------ GEMM in four passes + output transform + next input transform
+// ------------------------------------------------------------------ GEMM in six one-row passes + output transform + next input transform
 
 // A^T m for one transform row: six planes -> four values, on register PAIRS (elements 2 q, 2 q + 1 of the accumulator
 // tuples).  The running outputs are 128 independent pairs, not sixteen 16-register tuples: tuples need 16 consecutive

@@ -525,7 +525,7 @@ def main():
         roofline = roofline if f32s else {
             "bound": "mfma",
             "kernel": "3x3 256->256 tower conv = k_conv3x3_f16 (implicit GEMM, v_mfma_f32_32x32x16_f16)" if f16 else
-                      ("3x3 256->256 tower conv (Winograd F(4x4,3x3) in four passes on v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)" if f43 else
+                      ("3x3 256->256 tower conv (Winograd F(4x4,3x3) in six one-row passes on v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)" if f43 else
                        "3x3 256->256 tower conv (Winograd F(3x3,3x3) on v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)"),
             "achieved": exe_tf, "peak": peak, "unit": "TFLOP/s",
             "frac": exe_tf / peak if exe_tf is not None else None,
