@@ -143,9 +143,9 @@ __device__ __forceinline__ void bt6(V x0, V x1, V x2, V x3, V x4, V x5, V* r) {
 // Those are at most T + 1 <= 8 rows at either end of a block, so the grid is again 2 x tile blocks, but a workgroup
 // takes EIGHT rows (0..7 or 56..63) x 32 lanes (16 channel groups): 4 passes of 64 channels instead of 16 of 16 over
 // 32 mostly idle tiles (the first form of this kernel: 0.30 ms per layer, a tenth of it); rows in place are not touched.
-template <bool FIXUP>
+template <bool FIXUP, int X = 0>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, float* __restrict__ vimg,
-                                                  const int* __restrict__ d_count, int N, int T, int tb0, int tb1) {
+                                                  const int* __restrict__ d_count, int N, int T, int tb0, int tb1, int split) {
   constexpr int TPB = FIXUP ? 8 : 32;            // tile rows per workgroup
   constexpr int LPT = 256 / TPB;                 // lanes per tile: 8 / 32
   constexpr int GP = LPT / 2;                    // channel groups per pass: 4 / 16
@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   __shared__ __attribute__((aligned(16))) float img[GP * IMG];
   const int P = N * N, TT = T * T;
   const long Mt = (long)(*d_count) * TT;
-  const int tb = tb0 + (int)(blockIdx.x >> 1), part = blockIdx.x & 1;      // tile blocks [tb0, tb1) of the batch
+  // split (FIXUP): the channel passes of a workgroup's rows go to (kC / 4) / GP workgroups of their own
+  const int bx = split ? (int)blockIdx.x / split : (int)blockIdx.x;
+  const int pbeg = split ? (int)blockIdx.x % split : 0, pend = split ? pbeg + 1 : (kC / 4) / GP;
+  const int tb = tb0 + (bx >> 1), part = bx & 1;      // tile blocks [tb0, tb1) of the batch
   if (tb >= tb1) return;
   const int RPB = w4_block_rows(T, tb);
   const long tbase = w4_block_base(T, tb);
@@ -165,20 +168,29 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   const int row = row0 + tl;
   const long tile = tbase + row;
   bool live = row < RPB && tile < Mt;
-  const int b = live ? (int)(tile / TT) : 0, t = live ? (int)(tile % TT) : 0;
+  // (tile numbers fit 32 bits: the launcher checks; a 64-bit division is ~120 instructions)
+  const int b = live ? (int)((unsigned)tile / (unsigned)TT) : 0, t = live ? (int)((unsigned)tile % (unsigned)TT) : 0;
   const int ti = t / T, tj = t % T;
   if (FIXUP && live && w4_tile_fused(T, row, ti, tj)) live = false;       // in place already
   // (paired packing: a block that starts or ends on a board boundary has nothing to fix at that end)
   if (FIXUP && !__syncthreads_or(live)) return;
+  // patch point (u, v) = board point (4 ti - 1 + u, 4 tj - 1 + v): one base + a wave-uniform step; off the board (or a
+  // lane without a tile) -> -1.  Straight-line selects: the 36 x 4 branches hipcc makes of the obvious form were a third
+  // of the fix-up's instructions.
   int off[36];
+  {
+    const int pi0 = 4 * ti - 1, pj0 = 4 * tj - 1;
+    const int base = (b * P + pi0 + N * pj0) * kC;                         // < 2^31 (checked by the launcher)
 #pragma unroll
-  for (int u = 0; u < 6; ++u)
+    for (int u = 0; u < 6; ++u) {
+      const bool oku = live & ((unsigned)(pi0 + u) < (unsigned)N);
 #pragma unroll
-    for (int v = 0; v < 6; ++v) {
-      const int pi = 4 * ti - 1 + u, pj = 4 * tj - 1 + v;
-      const bool ok = live && pi >= 0 && pi < N && pj >= 0 && pj < N;
-      off[u * 6 + v] = ok ? (b * P + pi + N * pj) * kC : -1;               // < 2^31 (checked by the launcher)
+      for (int v = 0; v < 6; ++v) {
+        const bool ok = oku & ((unsigned)(pj0 + v) < (unsigned)N);
+        off[u * 6 + v] = ok ? base + (u + N * v) * kC : -1;
+      }
     }
+  }
   float* mine = img + sl * IMG + tl * 4 + 2 * ((h + (row >> 4)) & 1);
   float* gdst = vimg + (long)tb * W4BLOCK + row0 * 4;
   constexpr int CPR = 256 / TPB;                                           // chunks copied out per round
@@ -187,15 +199,19 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   if (FIXUP) {      // only the rows this kernel computed leave (a dead row inside the range is written as zeros)
     const int crow = row0 + cl;
     const long ctile = tbase + crow;
-    const int ct = (int)(ctile % TT);
+    const int ct = (int)((unsigned)ctile % (unsigned)TT);
     copy_row = !(crow < RPB && ctile < Mt && w4_tile_fused(T, crow, ct / T, ct % T));
   }
-  for (int pass = 0; pass < (kC / 4) / GP; ++pass) {
+  for (int pass = pbeg; pass < pend; ++pass) {
     const int ch = (pass * GP + sl) * 4 + 2 * h;
     f32x2 d[36];
 #pragma unroll
-    for (int q = 0; q < 36; ++q)
-      d[q] = off[q] >= 0 ? *reinterpret_cast<const f32x2*>(x + off[q] + ch) : (f32x2){0.f, 0.f};
+    for (int q = 0; q < 36; ++q) {
+      if (X == 2) { d[q] = (f32x2){(float)off[q], (float)ch}; continue; }
+      // every lane loads (an off-board point reads x[ch]: in bounds, discarded): 36 loads in flight, no branch per load
+      const f32x2 got = *reinterpret_cast<const f32x2*>(x + (off[q] >= 0 ? off[q] : 0) + ch);
+      d[q] = off[q] >= 0 ? got : (f32x2){0.f, 0.f};
+    }
     f32x2 tx[36];
 #pragma unroll
     for (int v = 0; v < 6; ++v) {
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
 #pragma unroll
       for (int i = 0; i < 6; ++i) tx[i * 6 + v] = r[i];
     }
-    if (pass) __syncthreads();                     // the previous pass has left the LDS image
+    if (pass != pbeg) __syncthreads();             // the previous pass has left the LDS image
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       f32x2 r[6];
@@ -222,6 +238,10 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
       w4_slot(pl / 6, pl % 6, pass * GP + s4, stage, unit);
       f32x4* gp = reinterpret_cast<f32x4*>(gdst + (long)stage * W4HALF + unit * W4UNIT + cl * 4);
       if (FIXUP && !copy_row) continue;
+      if (X == 1 && v[0] != 12345.f) continue;
+      // FIXUP: 128-byte pieces 1 KB apart -- as plain stores they merge in L2 and leave with the kernel's write-back
+      // (0.155 -> 0.12 ms per layer at 2048 boards of 19x19 against the streaming form, which X == 3 keeps for timing)
+      if (FIXUP && X != 3) { *gp = v; continue; }
       __builtin_nontemporal_store(v, gp);
     }
   }
@@ -727,9 +747,18 @@ void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, 
   wino4_check(bcap, N);
   if (fixup) {
     AGZ_REQUIRE(!w4_whole_boards(T) && T + 1 <= 8, AGZ_BAD_ARGUMENT, "fix-up transform: dense tile blocks, at most 8 rows at a block's ends");
-    hipLaunchKernelGGL((k_wino4_in<true>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1);
+    int split = 0;
+#ifdef AGZ_FIXUP_EXPERIMENTS
+    static const int fx = getenv("AGZ_WINO4_FX") ? atoi(getenv("AGZ_WINO4_FX")) : 0;      // 1 no stores, 2 no loads, 3 streaming stores, 4 no kernel, 5 split
+    if (fx == 4) return;
+    if (fx == 5) split = 4;
+    if (fx == 1) { hipLaunchKernelGGL((k_wino4_in<true, 1>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, 0); return; }
+    if (fx == 3) { hipLaunchKernelGGL((k_wino4_in<true, 3>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, 0); return; }
+    if (fx == 2) { hipLaunchKernelGGL((k_wino4_in<true, 2>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, 0); return; }
+#endif
+    hipLaunchKernelGGL((k_wino4_in<true>), dim3(2 * (tb1 - tb0) * (split ? split : 1)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, split);
   } else {
-    hipLaunchKernelGGL((k_wino4_in<false>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1);
+    hipLaunchKernelGGL((k_wino4_in<false>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, 0);
   }
 }
 
