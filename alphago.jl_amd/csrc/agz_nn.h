@@ -131,6 +131,8 @@ class Net {
   int tower_streams_ = 2;
   hipStream_t streamx_[kMaxTowerStreams - 1] = {nullptr, nullptr, nullptr};      // chains 1.. (chain 0 runs on stream_)
   hipEvent_t ev_fork_ = nullptr, ev_join_[kMaxTowerStreams - 1] = {nullptr, nullptr, nullptr};
+  bool fork_chains(int parts);                 // side streams wait for stream_; true if this tower is being timed
+  void join_chains(int parts, bool timed_tower);      // stream_ waits for the side streams
   DevBuf<float> d_uwino_s_, d_scale_s_;        // split form: weights as halves, scale x 1 / (operand scales)
   bool packed_split_ = false;
   DevBuf<float> d_uwino_, d_vimg_, d_vimg2_;   // transformed weights (stage images) / transformed activations (ping-pong)

@@ -650,6 +650,38 @@ void launch_conv3x3_direct_taps(const float* x, const float* wt, const float* on
   hipLaunchKernelGGL(k_sum_taps, dim3(g), dim3(256), 0, s, (const float*)part, stride, shift, y, d_count, N * N);
 }
 
+// Tower layer chains (agz_net_set_tower_streams): chain 0 runs on stream_, chains 1.. on streams of their own that wait for
+// everything enqueued so far (fork) and that stream_ waits for afterwards (join).  With more than one chain the layers
+// overlap, so the profile keeps ONE event pair around the whole tower (2 * tower layers).  Returns whether this tower is
+// being timed.
+bool Net::fork_chains(int parts) {
+  const bool pt = prof_on_ && prof_n_ < kProfMax;
+  if (parts <= 1) return pt;
+  if (!ev_fork_) AGZ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+  for (int i = 0; i + 1 < parts; ++i)
+    if (!streamx_[i]) {
+      AGZ_HIP(hipStreamCreateWithFlags(&streamx_[i], hipStreamNonBlocking));
+      AGZ_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
+    }
+  if (pt) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
+  AGZ_HIP(hipEventRecord(ev_fork_, stream_));
+  for (int i = 0; i + 1 < parts; ++i) AGZ_HIP(hipStreamWaitEvent(streamx_[i], ev_fork_, 0));
+  return pt;
+}
+
+void Net::join_chains(int parts, bool pt) {
+  if (parts <= 1) return;
+  for (int i = 0; i + 1 < parts; ++i) {
+    AGZ_HIP(hipEventRecord(ev_join_[i], streamx_[i]));
+    AGZ_HIP(hipStreamWaitEvent(stream_, ev_join_[i], 0));
+  }
+  if (pt) {
+    (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
+    prof_mult_[prof_n_] = 2 * tower_;
+    prof_fwd_of_[prof_n_++] = prof_fwd_;
+  }
+}
+
 void Net::check_async_error() {
   if (tower_err_ && *tower_err_) {
     const int err = *tower_err_;
@@ -744,18 +776,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         // (a chain should still fill the chip a few times over: at least ~4 workgroup rounds = 256 tile blocks each)
         const long tblocks = ((long)bcap * ((N_ + 3) / 4) * ((N_ + 3) / 4) + 63) / 64;
         const int parts = (int)std::max<long>(1, std::min<long>(tower_streams_, tblocks / 256));
-        if (parts > 1 && !ev_fork_) AGZ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        for (int i = 0; i + 1 < parts; ++i)
-          if (!streamx_[i]) {
-            AGZ_HIP(hipStreamCreateWithFlags(&streamx_[i], hipStreamNonBlocking));
-            AGZ_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
-          }
-        const bool pt = prof_on_ && prof_n_ < kProfMax;
-        if (parts > 1) {
-          if (pt) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);        // (the whole tower between one event pair)
-          AGZ_HIP(hipEventRecord(ev_fork_, stream_));
-          for (int i = 0; i + 1 < parts; ++i) AGZ_HIP(hipStreamWaitEvent(streamx_[i], ev_fork_, 0));
-        }
+        const bool pt = fork_chains(parts);
         for (int part = 0; part < parts; ++part) {
           hipStream_t st = part == 0 ? stream_ : streamx_[part - 1];
           float *pa = a, *pb = b, *vc = vcur, *vn = vnxt;
@@ -777,17 +798,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
             std::swap(pa, pb);
           }
         }
-        if (parts > 1) {
-          for (int i = 0; i + 1 < parts; ++i) {
-            AGZ_HIP(hipEventRecord(ev_join_[i], streamx_[i]));
-            AGZ_HIP(hipStreamWaitEvent(stream_, ev_join_[i], 0));
-          }
-          if (pt) {
-            (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
-            prof_mult_[prof_n_] = 2 * tower_;
-            prof_fwd_of_[prof_n_++] = prof_fwd_;
-          }
-        }
+        join_chains(parts, pt);
         if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
       } else {
       if (stem_wino) {
@@ -839,18 +850,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       const int chains33 = tower_streams_;
       const long tblocks3 = ((long)bcap * ((N_ + 2) / 3) * ((N_ + 2) / 3) + 62) / 63;
       const int parts = dense ? 1 : (int)std::max<long>(1, std::min<long>(std::min(chains33, (int)kMaxTowerStreams), tblocks3 / 256));
-      if (parts > 1 && !ev_fork_) AGZ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-      for (int i = 0; i + 1 < parts; ++i)
-        if (!streamx_[i]) {
-          AGZ_HIP(hipStreamCreateWithFlags(&streamx_[i], hipStreamNonBlocking));
-          AGZ_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
-        }
-      const bool pt = prof_on_ && prof_n_ < kProfMax;
-      if (parts > 1) {
-        if (pt) (void)hipEventRecord(prof_ev_[2 * prof_n_], stream_);
-        AGZ_HIP(hipEventRecord(ev_fork_, stream_));
-        for (int i = 0; i + 1 < parts; ++i) AGZ_HIP(hipStreamWaitEvent(streamx_[i], ev_fork_, 0));
-      }
+      const bool pt = fork_chains(parts);
       for (int part = 0; part < parts; ++part) {
         hipStream_t st = part == 0 ? stream_ : streamx_[part - 1];
         float *pa = a, *pb = b;
@@ -872,17 +872,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
           std::swap(pa, pb);
         }
       }
-      if (parts > 1) {
-        for (int i = 0; i + 1 < parts; ++i) {
-          AGZ_HIP(hipEventRecord(ev_join_[i], streamx_[i]));
-          AGZ_HIP(hipStreamWaitEvent(stream_, ev_join_[i], 0));
-        }
-        if (pt) {
-          (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
-          prof_mult_[prof_n_] = 2 * tower_;
-          prof_fwd_of_[prof_n_++] = prof_fwd_;
-        }
-      }
+      join_chains(parts, pt);
       if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
       }
       }
