@@ -47,7 +47,7 @@ def _positions(rng, B):
     return [positions[i] for i in rng.choice(len(positions), B, replace=False)]
 
 
-@pytest.mark.parametrize("winograd", [1, 0])
+@pytest.mark.parametrize("winograd", [1, 2, 0])      # 1: F(4x4,3x3) at this size; 2: F(3x3,3x3) only (dense blocks); 0: direct
 def test_c4_forward_f32_tower20_19x19(winograd):
     B, A = 16, N19 * N19 + 1
     onet, rng = _deep_net(41)

@@ -70,11 +70,12 @@ def test_forward_matches_oracle(N, tower, B, winograd):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32s"])
-@pytest.mark.parametrize("N", [3, 4, 6, 8, 10, 12, 13, 16, 19])
+@pytest.mark.parametrize("N", [3, 4, 6, 8, 10, 12, 13, 15, 16, 17, 18, 19])
 def test_every_tiling_class_of_the_winograd_tower(N, precision):
     """Tile blocks hold whole boards for N <= 12 (T*T = 1, 4, 9, 16 tiles per board: 64, 64, 63, 64 rows used,
     next layer's input transform fused into the GEMM epilogue) and are packed densely above (N = 13..15: 25
-    tiles, 16..18: 36, 19: 49 -- or fewer, larger tiles where F(4x4,3x3) takes over; the epilogue emits the V of every
+    tiles, 16..18: 36, 19: 49 -- the f32s rows; exact f32 runs F(4x4,3x3) from 13x13 on: 16 tiles per board and four
+    whole boards per block for N = 13..16, 25 tiles and five boards per block PAIR for N = 17..19; the epilogue emits the V of every
     tile whose input patch lies inside its block and a fix-up transform does the block ends); boards whose side is not
     a multiple of the tile have tiles hanging over the edge.  One parity check per class, batch sizes that leave a
     partial last block; a position's output must not depend on its batch row (which decides, for dense blocks, which
