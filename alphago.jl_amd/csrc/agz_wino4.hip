@@ -142,7 +142,7 @@ __device__ __forceinline__ void bt6(V x0, V x1, V x2, V x3, V x4, V x5, V* r) {
 // FIXUP (dense tile blocks only): only the tiles the previous layer's GEMM epilogue could not emit (!w4_tile_fused).
 // Those are at most T + 1 <= 8 rows at either end of a block, so the grid is again 2 x tile blocks, but a workgroup
 // takes EIGHT rows (0..7 or 56..63) x 32 lanes (16 channel groups): 4 passes of 64 channels instead of 16 of 16 over
-// 32 mostly idle tiles (the first form of this kernel: 0.30 ms per layer, a tenth of it); rows in place are not touched.
+// 32 mostly idle tiles (the first form of this kernel: 0.30 ms per layer, a tenth of it); whole 128-byte lines are written.
 template <bool FIXUP, int X = 0>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T, int tb0, int tb1, int split) {
@@ -171,9 +171,11 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   // (tile numbers fit 32 bits: the launcher checks; a 64-bit division is ~120 instructions)
   const int b = live ? (int)((unsigned)tile / (unsigned)TT) : 0, t = live ? (int)((unsigned)tile % (unsigned)TT) : 0;
   const int ti = t / T, tj = t % T;
-  if (FIXUP && live && w4_tile_fused(T, row, ti, tj)) live = false;       // in place already
-  // (paired packing: a block that starts or ends on a board boundary has nothing to fix at that end)
-  if (FIXUP && !__syncthreads_or(live)) return;
+  // FIXUP: nothing to do if every tile of these eight rows got its V from the GEMM epilogue (paired packing: a block
+  // that starts or ends on a board boundary has nothing to fix at that end).  Otherwise ALL eight rows are transformed
+  // and stored -- the rows in place get the same bits again (one arithmetic, bt6) -- so that the stores are whole
+  // 128-byte lines: with the rows in place masked out they were 96-byte pieces and L2 fetched every line to merge them.
+  if (FIXUP && !__syncthreads_or(live && !w4_tile_fused(T, row, ti, tj))) return;
   // patch point (u, v) = board point (4 ti - 1 + u, 4 tj - 1 + v): one base + a wave-uniform step; off the board (or a
   // lane without a tile) -> -1.  Straight-line selects: the 36 x 4 branches hipcc makes of the obvious form were a third
   // of the fix-up's instructions.
@@ -195,13 +197,6 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   float* gdst = vimg + (long)tb * W4BLOCK + row0 * 4;
   constexpr int CPR = 256 / TPB;                                           // chunks copied out per round
   const int cq = threadIdx.x / TPB, cl = threadIdx.x % TPB;
-  bool copy_row = true;
-  if (FIXUP) {      // only the rows this kernel computed leave (a dead row inside the range is written as zeros)
-    const int crow = row0 + cl;
-    const long ctile = tbase + crow;
-    const int ct = (int)((unsigned)ctile % (unsigned)TT);
-    copy_row = !(crow < RPB && ctile < Mt && w4_tile_fused(T, crow, ct / T, ct % T));
-  }
   for (int pass = pbeg; pass < pend; ++pass) {
     const int ch = (pass * GP + sl) * 4 + 2 * h;
     f32x2 d[36];
@@ -237,7 +232,6 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
       int stage, unit;
       w4_slot(pl / 6, pl % 6, pass * GP + s4, stage, unit);
       f32x4* gp = reinterpret_cast<f32x4*>(gdst + (long)stage * W4HALF + unit * W4UNIT + cl * 4);
-      if (FIXUP && !copy_row) continue;
       if (X == 1 && v[0] != 12345.f) continue;
       // FIXUP: 128-byte pieces 1 KB apart -- as plain stores they merge in L2 and leave with the kernel's write-back
       // (0.155 -> 0.12 ms per layer at 2048 boards of 19x19 against the streaming form, which X == 3 keeps for timing)

@@ -7,6 +7,6 @@ cp alphago.jl_amd/libagz.so /tmp/libagz_keep.so
 cp gpurun_ab/libagz_FX.so alphago.jl_amd/libagz.so
 for x in ${XS:-0 4 1 2 5 0 4 5}; do
   echo -n "FX=$x "
-  AGZ_WINO4_FX=$x python tools/nn_micro.py --board 19 --tower 4 --batches $B --algos 1 --iters 5 2>&1 | grep forward_ms | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('conv_ms', round(d['conv_ms_same_layer_loop'],4), 'forward_ms', round(d['forward_ms'],3))"
+  AGZ_WINO4_FX=$x python tools/nn_micro.py --board 19 --tower 4 --batches $B --algos 1 --iters ${ITERS:-5} 2>&1 | grep forward_ms | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('conv_ms', round(d['conv_ms_same_layer_loop'],4), 'forward_ms', round(d['forward_ms'],3))"
 done
 cp /tmp/libagz_keep.so alphago.jl_amd/libagz.so
