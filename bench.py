@@ -418,7 +418,9 @@ def main():
             "capped": bool(warm_games < G or gd["games_finished"] < G), "cap_seconds": args.generation_seconds,
             "power": gpower,
             "note": "generation_rate counts the moves of the games that ENDED in the window (8d), steady_state_rate the moves "
-                    "PLAYED in it (bench.py's `value` definition); they differ while the population of game ages is not stationary",
+                    "PLAYED in it (bench.py's `value` definition); they differ while the population of game ages is not stationary: in this bounded leg every game started at once and "
+                    "the window holds the FIRST (shortest) endings, so generation_rate here is a lower bound; a whole generation of "
+                    "1024 games (tools/generation.py, ~5 min: profiles/r04_generation.json) gave 406 positions/s by 8d's definition",
         }
         eng.records_clear()
 
