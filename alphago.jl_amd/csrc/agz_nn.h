@@ -232,10 +232,12 @@ size_t wino4_v_floats(int bcap, int N);
 // x -> V (all tiles), or with fixup only the tiles the previous GEMM's epilogue could not emit (dense blocks)
 void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s, bool fixup, int part = 0,
                      int parts = 1);
-// V, U -> y (if y != NULL) and / or the next layer's V (if vnext != NULL)
+// V, U -> y (if y != NULL) and / or the next layer's V (if vnext != NULL).  y_for_fixup_only (five boards per block pair,
+// no residual): y is stored only where launch_wino4_in(fixup) will read it -- 28 of a pair's 125 rows
 void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
                        float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s, int part = 0,
-                       int parts = 1);
+                       int parts = 1, bool y_for_fixup_only = false);
+bool wino4_paired(int N);                    // five boards per two tile blocks (N = 17..19)
 // (part / parts: the part-th of `parts` ranges of tile blocks, cut at board boundaries: ranges are independent layer chains)
 
 // fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged

@@ -784,8 +784,9 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
             const int l1 = 2 * blk, l2 = 2 * blk + 1;
             const bool last = blk + 1 == tower_;
             auto layer1 = [&] {
+              // (conv1's y is read by the fix-up transform only: with paired packing it is stored only there)
               launch_wino4_gemm(vc, d_uwino4_.p + per4 * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, dense4 ? t : nullptr,
-                                vn, d_count, bcap, N_, 1, st, part, parts);
+                                vn, d_count, bcap, N_, 1, st, part, parts, dense4 && wino4_paired(N_));
               if (dense4) launch_wino4_in(t, vn, d_count, bcap, N_, st, true, part, parts);
             };
             auto layer2 = [&] {

@@ -281,7 +281,7 @@ template <int MODE, int X>
 __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
-    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu, int tb0, int tb1) {
+    float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu, int tb0, int tb1y) {
   __shared__ __attribute__((aligned(256))) float lds[3 * W4STAGE];      // 144 KB: stage buffers, then the half image
   __shared__ int ptab[W4T * 16];            // element offset of output point X = k * 64 + row in y / res, or -1
   __shared__ __attribute__((aligned(256))) float zeros[64];      // what phase 2 reads for a patch point off the board
@@ -293,6 +293,8 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   const int bid = blockIdx.x;
   const int xcd = bid & 7, jb = bid >> 3;
   const int cb = jb & 3;
+  // (bit 30 of the last argument: y is wanted only where the fix-up transform reads it -- see the point table)
+  const int tb1 = tb1y & 0x3fffffff, ypart = tb1y >> 30;
   const int tb = tb0 + xcd + 8 * (jb >> 2);      // this launch covers tile blocks [tb0, tb1) of the batch
   if (tb >= tb1) return;
   const int RPB = w4_block_rows(T, tb);
@@ -328,11 +330,14 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   for (int j = 0; j < 12; ++j) dma(0, 0, j);
 
   if (tid < 64) zeros[tid] = 0.f;
+  // ypart (conv1 of a block with paired packing: y is read by the fix-up transform only): the eight rows at the pair's board
+  // cut and the T + 1 rows of neighbours on either side -- rows 50.. of the even block, ..13 of the odd one
+  const int yrow0 = ypart && !(tb & 1) ? 50 : 0, yrows = (ypart && (tb & 1) ? 14 : RPB) - yrow0;
   for (int idx = tid; idx < W4T * 16; idx += 256) {     // (published by the barrier in front of the first operand reads)
     const int row = idx & (W4T - 1), k = idx >> 6;
     const long tile = tbase + row;
     int off = -1;
-    if (row < RPB && tile < Mt) {
+    if ((unsigned)(row - yrow0) < (unsigned)yrows && tile < Mt) {
       const unsigned tile32 = (unsigned)tile, b = tile32 / (unsigned)TT, t = tile32 - b * (unsigned)TT;
       const unsigned ti = t / (unsigned)T;
       const int pi = (int)(4 * ti) + (k >> 2), pj = (int)(4 * (t - ti * T)) + (k & 3);
@@ -342,7 +347,6 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   }
 #pragma unroll
   for (int j = 0; j < 12; ++j) dma(1, 1, j);
-
   f32x16 acc[6];
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
   const int aoff = w4_off(arow, hi), boff = W4HALF + w4_off(brow, hi);
@@ -715,6 +719,7 @@ static long wino4_blocks(int bcap, int T) {
 }
 size_t wino4_v_floats(int bcap, int N) { return (size_t)wino4_blocks(bcap, (N + 3) / 4) * W4BLOCK; }
 bool wino4_whole_boards(int N) { return w4_whole_boards((N + 3) / 4); }
+bool wino4_paired(int N) { return w4_paired((N + 3) / 4); }
 // multiplies per output point: F(4x4,3x3) against F(3x3,3x3); the larger tile pays from 13x13 up
 bool wino4_applies(int N) { return N >= 13; }
 
@@ -758,7 +763,7 @@ void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, 
 
 // y == nullptr: the activations are not needed in HBM; vnext == nullptr: no next Winograd layer
 void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
-                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s, int part, int parts) {
+                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s, int part, int parts, bool ypart) {
   const int T = (N + 3) / 4;
   int tb0, tb1;
   wino4_range((int)wino4_blocks(bcap, T), part, parts, tb0, tb1);
@@ -768,7 +773,11 @@ void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale,
   const dim3 grid(8 * per_xcd), block(256);
   wino4_check(bcap, N);
   AGZ_REQUIRE(y || vnext, AGZ_BAD_ARGUMENT, "F(4x4,3x3) GEMM: nothing to write");
-#define W4_LAUNCH(MODE_, X_) hipLaunchKernelGGL((k_wino4_gemm<MODE_, X_>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1)
+  // ypart: y only where the fix-up transform reads it (paired packing, no residual: conv1 of a block) -- bit 30 of the
+  // kernel's last argument
+  AGZ_REQUIRE(!ypart || (w4_paired(T) && y && !res && tb1 < (1 << 30)), AGZ_BAD_ARGUMENT, "F(4x4,3x3) GEMM: partial y needs paired packing and no residual");
+  const int tb1y = tb1 | (ypart ? 1 << 30 : 0);
+#define W4_LAUNCH(MODE_, X_) hipLaunchKernelGGL((k_wino4_gemm<MODE_, X_>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1y)
 #ifdef AGZ_TIMING_EXPERIMENTS
   static const int xp = getenv("AGZ_WINO4_X") ? atoi(getenv("AGZ_WINO4_X")) : 0;
   static int traced = 0;
