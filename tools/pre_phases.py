@@ -26,11 +26,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--games", type=int, default=1024)
+    ap.add_argument("--board", type=int, default=9)
+    ap.add_argument("--tower", type=int, default=10)
+    ap.add_argument("--readouts", type=int, default=400)
     args = ap.parse_args()
-    eng = ag.Engine(board_size=9, tower_height=10, games=args.games, num_readouts=400, seed=1, stagger_moves=60)
+    eng = ag.Engine(board_size=args.board, tower_height=args.tower, games=args.games, num_readouts=args.readouts, seed=1,
+                    stagger_moves=60)
     eng.init_synthetic(0)
     eng.start(0)
-    eng.step(65)
+    eng.step(args.readouts // 8 + 15)
     c0 = dict(zip(NAMES, eng.debug_counters().astype(float)))
     eng.step(args.steps)
     c1 = dict(zip(NAMES, eng.debug_counters().astype(float)))
