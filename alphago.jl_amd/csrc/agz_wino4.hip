@@ -145,7 +145,7 @@ __device__ __forceinline__ void bt6(V x0, V x1, V x2, V x3, V x4, V x5, V* r) {
 // 32 mostly idle tiles (the first form of this kernel: 0.30 ms per layer, a tenth of it); whole 128-byte lines are written.
 template <bool FIXUP, int X = 0>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, float* __restrict__ vimg,
-                                                  const int* __restrict__ d_count, int N, int T, int tb0, int tb1, int split) {
+                                                  const int* __restrict__ d_count, int N, int T, int tb0, int tb1) {
   constexpr int TPB = FIXUP ? 8 : 32;            // tile rows per workgroup
   constexpr int LPT = 256 / TPB;                 // lanes per tile: 8 / 32
   constexpr int GP = LPT / 2;                    // channel groups per pass: 4 / 16
@@ -154,10 +154,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   __shared__ __attribute__((aligned(16))) float img[GP * IMG];
   const int P = N * N, TT = T * T;
   const long Mt = (long)(*d_count) * TT;
-  // split (FIXUP): the channel passes of a workgroup's rows go to (kC / 4) / GP workgroups of their own
-  const int bx = split ? (int)blockIdx.x / split : (int)blockIdx.x;
-  const int pbeg = split ? (int)blockIdx.x % split : 0, pend = split ? pbeg + 1 : (kC / 4) / GP;
-  const int tb = tb0 + (bx >> 1), part = bx & 1;      // tile blocks [tb0, tb1) of the batch
+  const int tb = tb0 + (int)(blockIdx.x >> 1), part = blockIdx.x & 1;      // tile blocks [tb0, tb1) of the batch
   if (tb >= tb1) return;
   const int RPB = w4_block_rows(T, tb);
   const long tbase = w4_block_base(T, tb);
@@ -197,7 +194,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
   float* gdst = vimg + (long)tb * W4BLOCK + row0 * 4;
   constexpr int CPR = 256 / TPB;                                           // chunks copied out per round
   const int cq = threadIdx.x / TPB, cl = threadIdx.x % TPB;
-  for (int pass = pbeg; pass < pend; ++pass) {
+  for (int pass = 0; pass < (kC / 4) / GP; ++pass) {
     const int ch = (pass * GP + sl) * 4 + 2 * h;
     f32x2 d[36];
 #pragma unroll
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
 #pragma unroll
       for (int i = 0; i < 6; ++i) tx[i * 6 + v] = r[i];
     }
-    if (pass != pbeg) __syncthreads();             // the previous pass has left the LDS image
+    if (pass) __syncthreads();                     // the previous pass has left the LDS image
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       f32x2 r[6];
@@ -746,18 +743,16 @@ void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, 
   wino4_check(bcap, N);
   if (fixup) {
     AGZ_REQUIRE(!w4_whole_boards(T) && T + 1 <= 8, AGZ_BAD_ARGUMENT, "fix-up transform: dense tile blocks, at most 8 rows at a block's ends");
-    int split = 0;
 #ifdef AGZ_FIXUP_EXPERIMENTS
-    static const int fx = getenv("AGZ_WINO4_FX") ? atoi(getenv("AGZ_WINO4_FX")) : 0;      // 1 no stores, 2 no loads, 3 streaming stores, 4 no kernel, 5 split
+    static const int fx = getenv("AGZ_WINO4_FX") ? atoi(getenv("AGZ_WINO4_FX")) : 0;      // 1 no stores, 2 no loads, 3 streaming stores, 4 no kernel
     if (fx == 4) return;
-    if (fx == 5) split = 4;
-    if (fx == 1) { hipLaunchKernelGGL((k_wino4_in<true, 1>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, 0); return; }
-    if (fx == 3) { hipLaunchKernelGGL((k_wino4_in<true, 3>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, 0); return; }
-    if (fx == 2) { hipLaunchKernelGGL((k_wino4_in<true, 2>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, 0); return; }
+    if (fx == 1) { hipLaunchKernelGGL((k_wino4_in<true, 1>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1); return; }
+    if (fx == 3) { hipLaunchKernelGGL((k_wino4_in<true, 3>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1); return; }
+    if (fx == 2) { hipLaunchKernelGGL((k_wino4_in<true, 2>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1); return; }
 #endif
-    hipLaunchKernelGGL((k_wino4_in<true>), dim3(2 * (tb1 - tb0) * (split ? split : 1)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, split);
+    hipLaunchKernelGGL((k_wino4_in<true>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1);
   } else {
-    hipLaunchKernelGGL((k_wino4_in<false>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1, 0);
+    hipLaunchKernelGGL((k_wino4_in<false>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1);
   }
 }
 
