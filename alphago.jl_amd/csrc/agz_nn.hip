@@ -847,7 +847,8 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       // relu(BN2(conv2(relu(BN1(conv1(x))))) + x), resnet.jl:26-32.  With whole-board tile blocks the batch's tile blocks can
       // run as independent layer chains on several streams, like the F(4x4,3x3) tower's (above): agz_net_set_tower_streams,
       // default 2.  Measured on the 9x9 headline (8192 positions, the layer on the board's power limit), alternating runs
-      // on one box: 46.80 / 47.00 ms per step with one chain, 46.20 / 46.08 with two (-1.6 %), bit-identical outputs.
+      // on one box: 46.80 / 47.00 ms per step with one chain, 46.20 / 46.08 with two (-1.6 %), bit-identical outputs; a later
+      // sweep (tools/chains_sweep.sh): 46.8 / 47.7 with one, 46.4 / 46.6 with two, 46.6 / 46.8 with three, 47.0 / 47.0 with four.
       const int chains33 = tower_streams_;
       const long tblocks3 = ((long)bcap * ((N_ + 2) / 3) * ((N_ + 2) / 3) + 62) / 63;
       const int parts = dense ? 1 : (int)std::max<long>(1, std::min<long>(std::min(chains33, (int)kMaxTowerStreams), tblocks3 / 256));
