@@ -93,6 +93,36 @@ def test_internal_network_games_match_oracle(N, tower, readouts, games, slots, k
     eng.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_19x19_games_to_their_end_replay_on_the_oracle(precision):
+    """Whole 19x19 games through recycled slots (the F(4x4,3x3) tower with its layer chains / the fp16 tower; 16 readouts):
+    every game is filed once, every record replays legally on the oracle's rules and -- unless it was resigned -- ends by
+    two passes or at max_game_length = 505 with the result the oracle's Tromp-Taylor count gives for the final board.
+    (The pool is asked for explicitly: DESIGN.md 2, the default assumes a flatter policy than the synthetic network's.)"""
+    N, G, TOTAL = 19, 32, 40
+    eng = ag.Engine(board_size=N, tower_height=1, games=G, num_readouts=16, seed=33, record_capacity_games=TOTAL + 8,
+                    max_nodes_per_game=8192)
+    eng.init_synthetic(0)
+    eng.set_precision(precision)
+    recs, st = run(eng, TOTAL, max_steps=60000)
+    assert len(recs) == TOTAL and st["pool_exhausted"] == 0
+    assert sorted(r["game_id"] for r in recs) == list(range(TOTAL))
+    ended_by_length = 0
+    for r in recs:
+        pos = orc.make_pos(N)
+        for a in r["moves"]:
+            rc, pos = orc.play(pos, int(a))
+            assert rc == orc.OK
+        assert pos.n == r["num_moves"] <= 505
+        if not r["was_resign"]:
+            assert pos.done or pos.n >= 505
+            ended_by_length += not pos.done
+            assert r["result"] == orc.lib().or_result(C.byref(pos))
+    print(f"19x19 {precision}: {TOTAL} games, {sum(r['num_moves'] for r in recs)} moves, "
+          f"{sum(bool(r['was_resign']) for r in recs)} resigned, {ended_by_length} at max_game_length")
+    eng.close()
+
+
 def test_properties_at_scale():
     """9x9 / tower 2 / 64 games / 32 readouts: invariants that need no oracle"""
     N, A = 9, 82
