@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("resign_disable_fraction", C.c_double),
         ("seed", C.c_uint64), ("game_id_base", C.c_uint64), ("game_id_stride", C.c_uint64),
         ("max_nodes_per_game", C.c_int32), ("device", C.c_int32), ("external_network", C.c_int32),
-        ("reserved1", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
+        ("pool_policy", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
     ]
 
 
@@ -42,7 +42,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "steps", "positions", "games_started", "games_finished", "evals", "duplicate_evals",
         "terminal_visits", "root_visits", "nodes_in_use", "pool_exhausted", "resigned_games", "live_games",
-        "records_dropped")]
+        "records_dropped", "pool_short_searches", "peak_nodes_per_game", "stalled_games", "node_capacity")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -51,7 +51,7 @@ class Stats(C.Structure):
 class GameHeader(C.Structure):
     _fields_ = [("game_id", C.c_uint64), ("num_moves", C.c_int32), ("result", C.c_int32),
                 ("was_resign", C.c_int32), ("resign_disabled", C.c_int32), ("final_score", C.c_float),
-                ("reserved", C.c_int32)]
+                ("short_searches", C.c_int32)]
 
 
 class PositionInfo(C.Structure):
@@ -141,6 +141,8 @@ def load():
         "agz_records_packed_size": (i32, [E, P(i64)]),
         "agz_records_export_packed": (i32, [E, C.c_void_p, i64, i32]),
         "agz_records_clear": (i32, [E]),
+        "agz_slot_status": (i32, [E, i32p, i32p, i32p]),
+        "agz_slot_abandon": (i32, [E, i32]),
         "agz_arena_counts": (i32, [E, i32p]),
         "agz_net_select": (i32, [E, i32]),
         "agz_records_features": (i32, [E, i64, f32p]),

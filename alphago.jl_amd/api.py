@@ -419,7 +419,10 @@ class MCTSPlayer:
         return positions, [p.copy() for p in self.searches_pi], [self.result] * len(positions)
 
 
-GameRecord = namedtuple("GameRecord", "game_id moves searches_pi qs result result_string was_resign")
+# short_searches: moves of the game played on fewer than num_ro readouts because its node pool was full (0 = the game is
+# the reference's game; agz_config.pool_policy, include/agz.h)
+GameRecord = namedtuple("GameRecord", "game_id moves searches_pi qs result result_string was_resign short_searches",
+                        defaults=[0])
 
 
 def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, precision="f32", **cfg):
@@ -434,9 +437,10 @@ def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, precision="f32", 
     eng.start(games)
     while eng.records_count() < games:
         eng.step(16)
-        if eng.stats()["pool_exhausted"]:
+        if eng.stats()["stalled_games"]:      # only with pool_policy = AGZ_POOL_STALL: a game waits on its full pool
             eng.close()
-            raise _lib.AgzError(_lib.POOL_EXHAUSTED, "node pool exhausted; raise max_nodes_per_game")
+            raise _lib.AgzError(_lib.POOL_EXHAUSTED, "a game is waiting on a full node pool (pool_policy = stall): raise "
+                                                     "max_nodes_per_game or use the default policy")
     out = []
     for r in eng.records():
         if r["was_resign"]:
@@ -445,11 +449,8 @@ def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, precision="f32", 
             s = r["final_score"]
             rs = f"B+{s:.1f}" if s > 0 else f"W+{-s:.1f}" if s < 0 else "DRAW"
         out.append(GameRecord(r["game_id"], [from_flat(int(a), env) for a in r["moves"]], list(r["pis"]),
-                              r["qs"], r["result"], rs, bool(r["was_resign"])))
-    st = eng.stats()
+                              r["qs"], r["result"], rs, bool(r["was_resign"]), int(r["short_searches"])))
     eng.close()
-    if st["pool_exhausted"]:
-        raise _lib.AgzError(_lib.POOL_EXHAUSTED, "node pool exhausted; raise max_nodes_per_game")
     return out
 
 

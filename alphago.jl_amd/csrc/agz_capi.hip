@@ -226,6 +226,12 @@ agz_status agz_records_export_packed(agz_engine* e, void* dst, int64_t capacity,
   return guard(e, [&](agz::Engine& E) { E.records_export_packed(dst, capacity, is_device != 0); });
 }
 agz_status agz_records_clear(agz_engine* e) { return guard(e, [&](agz::Engine& E) { E.records_clear(); }); }
+agz_status agz_slot_status(agz_engine* e, int32_t* status_out, int32_t* nodes_out, int32_t* moves_out) {
+  return guard(e, [&](agz::Engine& E) { E.slot_status(status_out, nodes_out, moves_out); });
+}
+agz_status agz_slot_abandon(agz_engine* e, int32_t slot) {
+  return guard(e, [&](agz::Engine& E) { E.slot_abandon(slot); });
+}
 agz_status agz_records_features(agz_engine* e, int64_t k, float* out) {
   return guard(e, [&](agz::Engine& E) { E.record_features(k, out); });
 }
@@ -336,7 +342,7 @@ int32_t agz_abi_layout(const char* name, int32_t* out, int32_t cap) {
     AGZ_OFF(agz_config, dirichlet_noise_weight); AGZ_OFF(agz_config, resign_threshold);
     AGZ_OFF(agz_config, resign_disable_fraction); AGZ_OFF(agz_config, seed); AGZ_OFF(agz_config, game_id_base);
     AGZ_OFF(agz_config, game_id_stride); AGZ_OFF(agz_config, max_nodes_per_game); AGZ_OFF(agz_config, device);
-    AGZ_OFF(agz_config, external_network); AGZ_OFF(agz_config, reserved1);
+    AGZ_OFF(agz_config, external_network); AGZ_OFF(agz_config, pool_policy);
     AGZ_OFF(agz_config, record_capacity_games); AGZ_OFF(agz_config, arena_mode);
   } else if (n == "agz_stats") {
     AGZ_SZ(agz_stats);
@@ -344,12 +350,13 @@ int32_t agz_abi_layout(const char* name, int32_t* out, int32_t cap) {
     AGZ_OFF(agz_stats, games_finished); AGZ_OFF(agz_stats, evals); AGZ_OFF(agz_stats, duplicate_evals);
     AGZ_OFF(agz_stats, terminal_visits); AGZ_OFF(agz_stats, root_visits); AGZ_OFF(agz_stats, nodes_in_use);
     AGZ_OFF(agz_stats, pool_exhausted); AGZ_OFF(agz_stats, resigned_games); AGZ_OFF(agz_stats, live_games);
-    AGZ_OFF(agz_stats, records_dropped);
+    AGZ_OFF(agz_stats, records_dropped); AGZ_OFF(agz_stats, pool_short_searches);
+    AGZ_OFF(agz_stats, peak_nodes_per_game); AGZ_OFF(agz_stats, stalled_games); AGZ_OFF(agz_stats, node_capacity);
   } else if (n == "agz_game_header") {
     AGZ_SZ(agz_game_header);
     AGZ_OFF(agz_game_header, game_id); AGZ_OFF(agz_game_header, num_moves); AGZ_OFF(agz_game_header, result);
     AGZ_OFF(agz_game_header, was_resign); AGZ_OFF(agz_game_header, resign_disabled);
-    AGZ_OFF(agz_game_header, final_score); AGZ_OFF(agz_game_header, reserved);
+    AGZ_OFF(agz_game_header, final_score); AGZ_OFF(agz_game_header, short_searches);
   } else if (n == "agz_position_info") {
     AGZ_SZ(agz_position_info);
     AGZ_OFF(agz_position_info, n); AGZ_OFF(agz_position_info, to_play); AGZ_OFF(agz_position_info, ko);

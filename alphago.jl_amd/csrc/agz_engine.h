@@ -85,6 +85,8 @@ class Engine {
                 int B, float* out);
   float time_forward(int B, int iters);
   float time_conv(int B, int iters);
+  void slot_status(int32_t* status, int32_t* nodes, int32_t* moves);
+  void slot_abandon(int g);
 
   void debug_draws(uint64_t seed, uint64_t game, uint32_t move, int n, double alpha, double* out);
   void debug_math(int op, const double* x, const double* y, int n, double* out);

@@ -399,10 +399,13 @@ static void validate(const agz_config& c) {
   AGZ_REQUIRE(c.parallel_readouts >= 1 && c.parallel_readouts <= kMaxPar, AGZ_BAD_ARGUMENT,
               "parallel_readouts %d not in 1..%d", c.parallel_readouts, kMaxPar);
   AGZ_REQUIRE(!c.arena_mode || c.games % 2 == 0, AGZ_BAD_ARGUMENT, "arena_mode needs an even number of slots");
-  // reserved1 was `stagger_moves` until round 2 (now agz_debug_set_stagger): an old-ABI caller that still sets it must
-  // hear about it instead of silently getting un-staggered games
-  AGZ_REQUIRE(c.reserved1 == 0 && c.reserved0 == 0.f, AGZ_BAD_ARGUMENT,
-              "agz_config.reserved0/reserved1 must be 0 (reserved1 was stagger_moves: use agz_debug_set_stagger)");
+  // the word that is pool_policy now was `stagger_moves` until round 2 (agz_debug_set_stagger since) and a must-be-zero
+  // reserved1 until round 4: an old-ABI caller that still puts a move count there must hear about it
+  AGZ_REQUIRE(c.reserved0 == 0.f, AGZ_BAD_ARGUMENT, "agz_config.reserved0 must be 0");
+  AGZ_REQUIRE(c.pool_policy == AGZ_POOL_MOVE_EARLY || c.pool_policy == AGZ_POOL_STALL, AGZ_BAD_ARGUMENT,
+              "agz_config.pool_policy %d: AGZ_POOL_MOVE_EARLY (0) or AGZ_POOL_STALL (1); this word was stagger_moves / "
+              "reserved1 in earlier headers (use agz_debug_set_stagger)", c.pool_policy);
+  AGZ_REQUIRE(c.max_nodes_per_game >= 0, AGZ_BAD_ARGUMENT, "max_nodes_per_game %d", c.max_nodes_per_game);
 }
 
 Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
@@ -610,10 +613,47 @@ void Engine::stats(agz_stats* out) {
   out->resigned_games = (int64_t)c[CT_RESIGNED];
   out->root_visits = (int64_t)c[CT_ROOTVISITS];
   out->records_dropped = c[CT_RECORDED] > (unsigned long long)V_.fin_cap ? (int64_t)(c[CT_RECORDED] - V_.fin_cap) : 0;
+  out->pool_short_searches = (int64_t)c[CT_POOL_SHORT];
+  out->peak_nodes_per_game = (int64_t)c[CT_PEAK_NODES];
+  out->node_capacity = V_.cap;
   for (const auto& g : gs) {
     out->nodes_in_use += g.nodes_used;
+    out->peak_nodes_per_game = std::max<int64_t>(out->peak_nodes_per_game, g.nodes_used);
     out->live_games += (g.phase != G_RETIRED && g.phase != G_IDLE);
+    out->stalled_games += (g.err == AGZ_POOL_EXHAUSTED && g.phase == G_SEARCH);
   }
+}
+
+// Per slot: AGZ_OK, or AGZ_POOL_EXHAUSTED for a game that is waiting on a full node pool (AGZ_POOL_STALL, or nothing
+// to play yet); nodes its tree holds; moves it has played.  The host's side of "recoverable": look, then
+// agz_slot_abandon the games it gives up on -- or let AGZ_POOL_MOVE_EARLY (the default) keep them moving.
+void Engine::slot_status(int32_t* status, int32_t* nodes, int32_t* moves) {
+  std::vector<GameState> gs(V_.games);
+  AGZ_HIP(hipMemcpyAsync(gs.data(), V_.gs, sizeof(GameState) * gs.size(), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  for (int g = 0; g < V_.games; ++g) {
+    if (status) status[g] = gs[g].err;
+    if (nodes) nodes[g] = gs[g].nodes_used;
+    if (moves) moves[g] = gs[g].move_count;
+  }
+}
+
+// Drop the game a slot is playing, without a record: the slot claims the next game id at the next step (or retires
+// when the quota of agz_selfplay_start is used up).  Not for arena or single-tree (manual) slots.
+void Engine::slot_abandon(int g) {
+  AGZ_REQUIRE(g >= 0 && g < V_.games, AGZ_BAD_ARGUMENT, "slot %d of %d", g, V_.games);
+  AGZ_REQUIRE(!V_.arena, AGZ_BAD_ARGUMENT, "arena slots come in pairs: not abandonable one by one");
+  GameState G;
+  AGZ_HIP(hipMemcpyAsync(&G, V_.gs + g, sizeof(G), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  AGZ_REQUIRE(G.phase == G_SEARCH || G.phase == G_INIT || G.phase == G_INIT_WAIT, AGZ_BAD_ARGUMENT,
+              "slot %d is not playing a self-play game (phase %d)", g, G.phase);
+  G.phase = G_IDLE;
+  G.nleaves = 0;
+  G.npend = 0;
+  G.err = 0;
+  AGZ_HIP(hipMemcpyAsync(V_.gs + g, &G, sizeof(G), hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
 }
 
 // ---- records

@@ -26,7 +26,12 @@ inline void fill_dims(View& V, const agz_config& c) {
   V.arena = c.arena_mode ? 1 : 0;
   V.two_player = c.two_player_mode || c.arena_mode;       // evaluate(): both players are two_player_mode
   V.stagger = 0;                 // agz_debug_set_stagger (bench / soak tests only)
-  V.cap = c.max_nodes_per_game > 0 ? c.max_nodes_per_game : 16 * c.num_readouts + 256;
+  // default pool: with subtree reuse a game's tree settles near R / (1 - f), f = the played child's share of the root's
+  // visits (16 R covers f < 0.94); a sharp policy over a long game adds to that whatever R is, hence the term in the
+  // game length (19x19, 16-32 readouts, 500 moves needed ~8000 nodes: tools/soak_selfplay.py).  A full pool is handled
+  // by agz_config.pool_policy, not by stopping.
+  V.cap = c.max_nodes_per_game > 0 ? c.max_nodes_per_game : 16 * c.num_readouts + 256 + 16 * V.max_game_length;
+  V.pool_policy = c.pool_policy;
   V.fin_cap = c.record_capacity_games > 0 ? c.record_capacity_games : 2 * c.games + 64;
   V.total_games = 0;
   V.seed = c.seed;

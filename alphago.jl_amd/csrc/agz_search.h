@@ -889,7 +889,7 @@ AGZ_FN void game_start(W& w, const View& V, Scratch& S, int g, uint64_t game_id)
     G.rootN = 0.f; G.rootW = 0.f; G.target = 0.f; G.komi = V.komi;
     G.sel = 0; G.move_count = 0; G.nqs = 0; G.hist_len = 0;
     G.free_top = V.cap; G.garbage = 0; G.nleaves = 0; G.err = 0; G.result = 0; G.was_resign = 0; G.nodes_used = 0;
-    G.short_first = 0;
+    G.short_first = 0; G.short_searches = 0;
     G.phase = G_INIT;
   }
   w.sync();
@@ -944,7 +944,7 @@ AGZ_FN void game_finish(W& w, const View& V, Scratch& S, int g, int winner, int 
   if (w.leader()) {
     agz_game_header h;
     h.game_id = G.game_id; h.num_moves = nm; h.result = winner; h.was_resign = was_resign;
-    h.resign_disabled = G.resign_disabled; h.final_score = score; h.reserved = 0;
+    h.resign_disabled = G.resign_disabled; h.final_score = score; h.short_searches = G.short_searches;
     V.fin_hdr[slot] = h;
     G.result = winner; G.was_resign = was_resign; G.phase = G_IDLE;
   }
@@ -955,6 +955,27 @@ AGZ_FN void game_finish(W& w, const View& V, Scratch& S, int g, int winner, int 
   w.for_each(nm * V.A, [&](int i) { V.fin_pi[slot * mgl * V.A + i] = V.rec_pi[(long)g * mgl * V.A + i]; });
   w.sync();
   if (was_resign) w.count(&V.counters[CT_RESIGNED], 1);
+}
+
+// A game whose node pool refused an allocation in the last select phase (G.err).  The reference's tree is unbounded
+// (mcts.jl:140-147: a child is a fresh heap object); a fixed pool has to answer "and when it is full?".  With
+// AGZ_POOL_MOVE_EARLY the search of this move ends here: the move phase runs on the visits the root has -- re-rooting
+// hands the siblings' subtrees back -- and the shortened search is counted (agz_stats, game header).  That needs a
+// child to play: an expanded root with a visited board move (the soft pick normalises by the non-pass visits,
+// mcts_play.jl:64-67), or any visited child once the pick is the arg-max.  Otherwise, and always with AGZ_POOL_STALL,
+// the slot waits for the host (agz_slot_status / agz_slot_abandon); the other slots are not affected.
+template <class W>
+AGZ_FN bool pool_full_can_move(W& w, const View& V, int g) {
+  const GameState& G = V.gs[g];
+  if (G.err != AGZ_POOL_EXHAUSTED || V.pool_policy != AGZ_POOL_MOVE_EARLY) return false;
+  const long ri = node_index(V, g, G.root);
+  const NodeMeta rm = V.meta[ri];
+  if (!(rm.flags & NF_EXPANDED)) return false;
+  float s = 0.f;
+  w.for_each(V.P, [&](int a) { s += V.childN[ri * V.AP + a]; });
+  s = w.reduce_sum_f(s);
+  const bool argmax = V.two_player || rm.n >= V.tau;
+  return s > 0.f || (argmax && V.childN[ri * V.AP + V.P] > 0.f);
 }
 
 // The selfplay.jl:22-43 loop body between two readout phases, for a game whose budget is spent:
@@ -968,6 +989,13 @@ AGZ_FN void game_move_phase(W& w, const View& V, Scratch& S, int g) {
   // should_resign: Q_perspective(root) < resign_threshold (mcts_play.jl:124)
   const float q = G.rootW / (1.0f + G.rootN);
   const float qp = q * (float)rm.to_play;
+  w.count_max(&V.counters[CT_PEAK_NODES], (unsigned long long)G.nodes_used);
+  const bool early = G.rootN < G.target;          // only game_pre's full-pool rule sends a game here before its budget is spent
+  if (early) {
+    w.count(&V.counters[CT_POOL_SHORT], 1);
+    if (w.leader()) { G.short_searches = G.short_searches + 1; G.err = 0; }
+    w.sync();
+  }
   if ((double)qp < G.resign_threshold) {
     game_finish(w, V, S, g, -rm.to_play, 1, 0.f);
     return;
@@ -1236,7 +1264,7 @@ AGZ_FN void game_pre(W& w, const View& V, Scratch& S, int g) {
     return;
   }
   bool agz_moved = false;
-  if (G.phase == G_SEARCH && !(G.rootN < G.target)) { game_move_phase(w, V, S, g); agz_moved = true; }
+  if (G.phase == G_SEARCH && (!(G.rootN < G.target) || pool_full_can_move(w, V, g))) { game_move_phase(w, V, S, g); agz_moved = true; }
   (void)agz_moved;
   AGZ_STAMP_BEGIN_AGAIN(w);
   if (G.phase == G_IDLE) {
@@ -1430,6 +1458,7 @@ AGZ_FN void tree_op(W& w, const View& V, Scratch& S, const TreeArgs& T) {
         G.rootN = 0.f; G.rootW = 0.f; G.target = 0.f; G.komi = T.info.komi;
         G.sel = 0; G.move_count = 0; G.nqs = 0; G.hist_len = T.info.history_len;
         G.free_top = V.cap; G.garbage = 0; G.nleaves = 0; G.err = 0; G.result = 0; G.was_resign = 0; G.nodes_used = 0;
+        G.short_searches = 0;
         G.phase = G_MANUAL;
         G.resign_threshold = V.resign_threshold; G.resign_disabled = 0;
       }

@@ -62,6 +62,7 @@ struct GameState {
   int32_t arena_k;           // arena: games this slot has finished (= local index of the current one)
   int32_t garbage;           // nodes on the deferred-free stack (tail of the slot's free list)
   int32_t npend;             // leaves created by this step's select phase whose board update waits for k_expand
+  int32_t short_searches;    // moves of this game played before their budget was spent (full pool, AGZ_POOL_MOVE_EARLY)
 };
 
 constexpr int kMaxPend = 16;    // deferred leaf expansions per game and step (2 x parallel_readouts at most)
@@ -75,6 +76,8 @@ enum Counter : int {
   CT_T_FREE, CT_T_PICK, CT_T_CHILD, CT_T_REROOT, CT_T_NOISE, CT_T_MOVE_SELECT, CT_N_MOVE, CT_T_SELECT, CT_N_SELECT,
   CT_T_MOVE_MAX,   // max over games of one move phase + its select phase
   CT_T_CREATE, CT_N_CREATE,   // node_create_child (leaf expansion: board update in scratch), all callers
+  CT_POOL_SHORT,   // moves played early because the pool was full
+  CT_PEAK_NODES,   // max over games of nodes_used at the moment of a move
   CT_COUNT
 };
 
@@ -83,6 +86,7 @@ struct View {
   int N, P, PP, A, AP, LW, cap, games, par, maxd;
   int R, max_game_length, tau, two_player, stagger;
   int arena;           // evaluate() arena: slots 2i / 2i+1 are Black's / White's player of one game
+  int pool_policy;     // AGZ_POOL_MOVE_EARLY / AGZ_POOL_STALL
   int fin_cap;
   int64_t total_games;
   uint64_t seed, id_base, id_stride;

@@ -14,7 +14,7 @@ import struct
 
 import numpy as np
 
-HEADER = struct.Struct("<Qiiiifi")   # game_id, num_moves, result, was_resign, resign_disabled, final_score, reserved
+HEADER = struct.Struct("<Qiiiifi")   # game_id, num_moves, result, was_resign, resign_disabled, final_score, short_searches
 assert HEADER.size == 32
 
 
@@ -24,7 +24,7 @@ def pack_records(records, A):
     for r in records:
         n = int(len(r["moves"]))
         out += HEADER.pack(int(r["game_id"]), n, int(r["result"]), int(r["was_resign"]),
-                           int(r.get("resign_disabled", 0)), float(r.get("final_score", 0.0)), 0)
+                           int(r.get("resign_disabled", 0)), float(r.get("final_score", 0.0)), int(r.get("short_searches", 0)))
         out += np.ascontiguousarray(r["moves"], np.int16).tobytes()
         out += b"\0" * (-len(out) % 4)
         pis = np.ascontiguousarray(r["pis"], np.float32).reshape(n, A) if n else np.zeros((0, A), np.float32)
@@ -39,7 +39,7 @@ def unpack_records(buf, A):
     raw = buf.tobytes()
     out, off = [], 0
     while off + HEADER.size <= len(raw):
-        game_id, n, result, was_resign, resign_disabled, final_score, _ = HEADER.unpack_from(raw, off)
+        game_id, n, result, was_resign, resign_disabled, final_score, short = HEADER.unpack_from(raw, off)
         off += HEADER.size
         moves = np.frombuffer(raw, np.int16, n, off).copy()
         off += 2 * n
@@ -50,7 +50,8 @@ def unpack_records(buf, A):
         off += 4 * n
         off += -off % 8
         out.append(dict(game_id=game_id, num_moves=n, result=result, was_resign=was_resign,
-                        resign_disabled=resign_disabled, final_score=final_score, moves=moves, pis=pis, qs=qs))
+                        resign_disabled=resign_disabled, final_score=final_score, short_searches=short, moves=moves, pis=pis,
+                        qs=qs))
     return out
 
 

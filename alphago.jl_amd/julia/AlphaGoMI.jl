@@ -44,7 +44,7 @@ struct AgzConfig
   c_puct::Float64; dirichlet_noise_weight::Float64; resign_threshold::Float64
   resign_disable_fraction::Float64
   seed::UInt64; game_id_base::UInt64; game_id_stride::UInt64
-  max_nodes_per_game::Int32; device::Int32; external_network::Int32; reserved1::Int32
+  max_nodes_per_game::Int32; device::Int32; external_network::Int32; pool_policy::Int32
   record_capacity_games::Int32; arena_mode::Int32
 end
 
@@ -61,13 +61,14 @@ end
 
 struct AgzGameHeader
   game_id::UInt64; num_moves::Int32; result::Int32; was_resign::Int32; resign_disabled::Int32
-  final_score::Float32; reserved::Int32
+  final_score::Float32; short_searches::Int32
 end
 
-struct AgzStats            # agz_stats, include/agz.h: thirteen Int64 counters
+struct AgzStats            # agz_stats, include/agz.h: seventeen Int64 counters
   steps::Int64; positions::Int64; games_started::Int64; games_finished::Int64; evals::Int64
   duplicate_evals::Int64; terminal_visits::Int64; root_visits::Int64; nodes_in_use::Int64
   pool_exhausted::Int64; resigned_games::Int64; live_games::Int64; records_dropped::Int64
+  pool_short_searches::Int64; peak_nodes_per_game::Int64; stalled_games::Int64; node_capacity::Int64
 end
 
 mutable struct Engine
@@ -90,19 +91,32 @@ function stats(e::Engine)
   st[]
 end
 
-check_pool(e::Engine) = stats(e).pool_exhausted > 0 &&
-  error("libagz: node pool exhausted (status $AGZ_POOL_EXHAUSTED); raise max_nodes_per_game")
+# a self-play game whose node pool is full plays its move early by default (agz_config.pool_policy, counted in
+# stats(e).pool_short_searches and in the game's header); only a game that WAITS on its pool (AGZ_POOL_STALL, or the
+# arena, which drops such a game) is an error here
+check_pool(e::Engine) = (st = stats(e); (st.stalled_games > 0 || (e.cfg.arena_mode != 0 && st.pool_exhausted > 0)) &&
+  error("libagz: a game is waiting on a full node pool (status $AGZ_POOL_EXHAUSTED); raise max_nodes_per_game"))
+
+# agz_slot_status: per slot (status, nodes held, moves played); agz_slot_abandon drops the game in a slot
+function slot_status(e::Engine)
+  n = Int(e.cfg.games)
+  st, nd, mv = zeros(Int32, n), zeros(Int32, n), zeros(Int32, n)
+  check(e, ccall((:agz_slot_status, libagz), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}), e.handle, st, nd, mv))
+  st, nd, mv
+end
+slot_abandon!(e::Engine, slot::Integer) =
+  check(e, ccall((:agz_slot_abandon, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, slot))
 
 function Engine(; board_size = 19, tower_height = 19, games = 1, num_readouts = 800,
                 parallel_readouts = 8, two_player_mode = false, komi = 7.5, c_puct = 0.96,
                 dirichlet_noise_weight = 0.25, resign_threshold = -0.9,
                 resign_disable_fraction = 0.05, seed = 0, game_id_base = 0, game_id_stride = 1,
                 max_nodes_per_game = 0, device = 0, external_network = false,
-                record_capacity_games = 0, arena_mode = false)
+                record_capacity_games = 0, arena_mode = false, pool_policy = 0)
   cfg = AgzConfig(board_size, tower_height, games, num_readouts, parallel_readouts,
                   two_player_mode ? 1 : 0, komi, 0f0, c_puct, dirichlet_noise_weight,
                   resign_threshold, resign_disable_fraction, seed, game_id_base, game_id_stride,
-                  max_nodes_per_game, device, external_network ? 1 : 0, 0, record_capacity_games,
+                  max_nodes_per_game, device, external_network ? 1 : 0, pool_policy, record_capacity_games,
                   arena_mode ? 1 : 0)
   h = Ref{Ptr{Cvoid}}(C_NULL)
   st = ccall((:agz_engine_create, libagz), Int32, (Ref{AgzConfig}, Ref{Ptr{Cvoid}}), cfg, h)

@@ -9,7 +9,7 @@ positions) -> expand / back up, plus the per-move phase (resign check, pick, pla
 for the games whose 400-readout budget is spent.  A "position" = one self-play move that received
 its full 400 readouts inside the run.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: starts its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  value = positions played by all ranks / max-over-ranks time of
@@ -227,6 +227,48 @@ def cpu_baseline(N, tower, readouts, seconds):
     }
 
 
+def self_launch(n, single_device):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here -- N copies of
+    this very command, one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their
+    environment exactly as torch.distributed.run would set them -- and wait.  Rank 0 inherits this process's stdout
+    (the one JSON line); the other ranks' stdout goes to stderr.  The games are independent
+    (/root/reference/src/train.jl:56-57): nothing but the rendezvous address is shared.  Returns the exit status."""
+    import socket
+    import subprocess
+    if not single_device:
+        try:
+            import torch
+            have = torch.cuda.device_count()
+        except Exception:
+            have = 0
+        if have < n:
+            print(f"bench.py: --gpus {n} but {have} GPU(s) visible (one rank per GPU; --single-device-test puts every "
+                  f"rank on cuda:0 for a rehearsal)", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   AGZ_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and deadline is None:
+                rc, deadline = p.returncode, time.time() + 30.0        # one rank died: the others get 30 s to follow
+        if deadline is not None and time.time() > deadline:
+            for p in procs:                                            # (exactly the processes started above)
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    return rc or max((abs(p.returncode) for p in procs), default=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +307,15 @@ def main():
                     help="testing only: every rank uses cuda:0 and gloo, to exercise the multi-rank code path on a 1-GPU box")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher: be the launcher
+        sys.exit(self_launch(args.gpus, args.single_device_test))
+
+    # stdout carries exactly ONE JSON line: gloo / RCCL / the HIP runtime print banners on fd 1 from native code, so fd 1
+    # points at stderr for the whole run and the line goes out through a private copy of the original stdout
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
 
     import alphago_jl_amd as ag
@@ -276,7 +327,8 @@ def main():
         headline = (args.board, args.tower, args.readouts, args.games, args.precision) == (9, 10, 400, 1024, "f32")
         args.generation = 128 if (world == 1 and headline and args.stagger > 0) else 0
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} under a launcher that set WORLD_SIZE={world}: start {args.gpus} ranks, or "
+                         f"run `python bench.py --gpus {args.gpus}` with WORLD_SIZE unset and it starts them itself")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if args.single_device_test:
@@ -367,7 +419,13 @@ def main():
     elapsed = t1 - t0
     d = {k: s1[k] - s0[k] for k in ("positions", "evals", "duplicate_evals", "terminal_visits", "root_visits",
                                     "games_finished", "steps")}
+    per_rank = None
     if dist is not None:
+        mine = torch.tensor([d["positions"], elapsed, conv_ms / max(conv_n, 1)], dtype=torch.float64, device=rdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "positions": float(t[0]), "seconds": float(t[1]), "positions_per_s": float(t[0] / t[1]),
+                     "layer_ms": float(t[2])} for r, t in enumerate(x.tolist() for x in allr)]
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -488,8 +546,11 @@ def main():
         os.dup2(saved_fd, 1)
         os.close(saved_fd)
 
-    if s1["pool_exhausted"]:
-        raise SystemExit("node pool exhausted during the benchmark: results invalid")
+    if s1["stalled_games"] or s1["pool_short_searches"]:
+        # the default pool holds every tree of these workloads with room to spare (`pool` in the line says how much); a
+        # shortened or waiting search here means the number is not the reference's workload
+        raise SystemExit(f"node pool: {s1['pool_short_searches']} shortened searches, {s1['stalled_games']} waiting games "
+                         f"(capacity {s1['node_capacity']}): results invalid")
 
     if rank == 0:
         value = d["positions"] / elapsed
@@ -576,6 +637,8 @@ def main():
             "end_to_end_executed_mfma_frac": value * fpos * wino_ratio / (world * peak * 1e12),
             "roofline": roofline,
             "power": power,        # socket power and shader clock over the timed region (PowerSampler)
+            "pool": {"node_capacity": s1["node_capacity"], "peak_nodes_per_game": s1["peak_nodes_per_game"],
+                     "short_searches": s1["pool_short_searches"], "refused_allocations": s1["pool_exhausted"]},
         }
         if power and power.get("sclk_mhz") and not f16 and not f32s and exe_tf is not None:
             # what the nominal peak becomes at the clock the timed region actually ran at (the peak assumes 2.4 GHz)
@@ -585,6 +648,8 @@ def main():
                                              "note": "peak scaled from the 2.4 GHz nominal clock to the mean sampled sclk"}
         if generation is not None:
             out["generation"] = generation
+        if per_rank is not None:
+            out["per_rank"] = per_rank      # each rank's own clock over the same K steps (`value` uses the slowest)
         if exchange is not None:
             out["exchange"] = exchange
         if alt is not None:
@@ -595,7 +660,7 @@ def main():
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=line_out, flush=True)
     if exchange_hung:          # a stuck collective also blocks engine teardown: the line is out, leave
         sys.stdout.flush()
         os._exit(0)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AGZ_VERSION 100
+#define AGZ_VERSION 101
 
 typedef int32_t agz_status;
 #define AGZ_OK 0
@@ -43,6 +43,9 @@ typedef int32_t agz_status;
 #define AGZ_POOL_EXHAUSTED 8      /* a game's node pool overflowed (ours; no reference analogue) */
 #define AGZ_RCCL_ERROR 9
 #define AGZ_NOT_READY 10
+
+#define AGZ_POOL_MOVE_EARLY 0
+#define AGZ_POOL_STALL 1
 
 typedef struct agz_engine agz_engine;
 
@@ -67,10 +70,16 @@ typedef struct {
   uint64_t seed;                   /* draw-stream seed (include/agz_draws.h) */
   uint64_t game_id_base;           /* first global game id played by this engine */
   uint64_t game_id_stride;         /* id increment when a slot is recycled (= total slots) */
-  int32_t max_nodes_per_game;      /* 0 = auto (16*num_readouts + 256) */
+  int32_t max_nodes_per_game;      /* 0 = auto: 16*num_readouts + 256 + 16*max_game_length (see pool_policy) */
   int32_t device;                  /* HIP device ordinal */
   int32_t external_network;        /* 1: pi/v are supplied by the caller (duck-typed network) */
-  int32_t reserved1;               /* 0 (rounds 1-2 kept a bench-only knob here: now agz_debug_set_stagger, agz_debug.h) */
+  int32_t pool_policy;             /* what a game does when its node pool is full (the reference's tree is garbage-
+                                    * collected and unbounded, mcts.jl:140-147): AGZ_POOL_MOVE_EARLY (0, default) ends
+                                    * the search of the current move there and plays it from the visits it has -- counted
+                                    * in agz_stats.pool_short_searches and in the game's header; AGZ_POOL_STALL (1) never
+                                    * shortens a search: the slot waits (agz_slot_status) until the host abandons it
+                                    * (agz_slot_abandon).  Other slots keep stepping either way.  (This word was
+                                    * reserved1 = 0 until round 4, and a bench-only knob before that.) */
   int32_t record_capacity_games;   /* finished-game record slots kept on the device; 0 = auto */
   int32_t arena_mode;              /* 1: evaluate() arena -- slots 2i / 2i+1 are the Black / White player of one
                                     * game with networks 0 / 1 (agz_net_select); `games` must be even */
@@ -199,13 +208,24 @@ typedef struct {
   int64_t terminal_visits;     /* select_leaf hits on finished positions                */
   int64_t root_visits;         /* sum of N(root) increments                             */
   int64_t nodes_in_use;
-  int64_t pool_exhausted;      /* >0 => results invalid, raise max_nodes_per_game       */
+  int64_t pool_exhausted;      /* allocations refused by a full pool (see pool_policy)  */
   int64_t resigned_games;
   int64_t live_games;
   int64_t records_dropped;     /* finished games overwritten in the record ring since the last
                                 * agz_records_clear (ring = record_capacity_games): drain more often */
+  int64_t pool_short_searches; /* moves played before their readout budget was spent because the game's pool was
+                                * full (AGZ_POOL_MOVE_EARLY); 0 = every move had the reference's R readouts */
+  int64_t peak_nodes_per_game; /* largest tree any slot has held at the moment it moved (of max_nodes_per_game) */
+  int64_t stalled_games;       /* slots waiting on a full pool right now (AGZ_POOL_STALL, or no visited child to play) */
+  int64_t node_capacity;       /* max_nodes_per_game in effect */
 } agz_stats;
 agz_status agz_engine_stats(agz_engine* e, agz_stats* out);            /* synchronises */
+/* Per slot (arrays of `games` int32, any of them may be NULL): status = AGZ_OK or AGZ_POOL_EXHAUSTED (the game is
+ * waiting on a full node pool: agz_config.pool_policy), nodes its tree holds, moves it has played.  The reference has
+ * no analogue (its tree is unbounded, mcts.jl:140-147, mcts_play.jl:48); synchronises. */
+agz_status agz_slot_status(agz_engine* e, int32_t* status_out, int32_t* nodes_out, int32_t* moves_out);
+/* give up the game in `slot` without a record; the slot starts the next game id at the next step */
+agz_status agz_slot_abandon(agz_engine* e, int32_t slot);
 /* external-network mode (MCTSPlayer.network duck typing, mcts_play.jl:5,89): after a step's
  * select phase the caller reads the leaf feature tensor and supplies pi/v. */
 agz_status agz_selfplay_select(agz_engine* e, int32_t* nleaves_out);
@@ -220,7 +240,8 @@ typedef struct {
   int32_t was_resign;
   int32_t resign_disabled;
   float final_score;           /* score(position) when not resigned                       */
-  int32_t reserved;
+  int32_t short_searches;      /* moves of this game played on fewer than num_readouts readouts (full node pool,
+                                * AGZ_POOL_MOVE_EARLY); 0 for a game that is the reference's game */
 } agz_game_header;
 int64_t agz_records_count(agz_engine* e);                               /* synchronises */
 agz_status agz_records_header(agz_engine* e, int64_t k, agz_game_header* out);

@@ -8,7 +8,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CT = ["steps", "positions", "started", "finished", "evals", "dup", "terminal", "rootvisits",
-      "pool_exhausted", "resigned", "claimed", "recorded"]
+      "pool_exhausted", "resigned", "claimed", "recorded",
+      "t_free", "t_pick", "t_child", "t_reroot", "t_noise", "t_move_select", "n_move", "t_select", "n_select", "t_move_max",
+      "t_create", "n_create", "pool_short", "peak_nodes"]          # enum Counter of agz_state.h, in order
 
 
 class AgzConfig(C.Structure):
@@ -20,7 +22,7 @@ class AgzConfig(C.Structure):
         ("resign_disable_fraction", C.c_double),
         ("seed", C.c_uint64), ("game_id_base", C.c_uint64), ("game_id_stride", C.c_uint64),
         ("max_nodes_per_game", C.c_int32), ("device", C.c_int32), ("external_network", C.c_int32),
-        ("reserved1", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
+        ("pool_policy", C.c_int32), ("record_capacity_games", C.c_int32), ("arena_mode", C.c_int32),
     ]
 
 
@@ -54,7 +56,7 @@ class PositionInfo(C.Structure):
 class GameHeader(C.Structure):
     _fields_ = [("game_id", C.c_uint64), ("num_moves", C.c_int32), ("result", C.c_int32),
                 ("was_resign", C.c_int32), ("resign_disabled", C.c_int32), ("final_score", C.c_float),
-                ("reserved", C.c_int32)]
+                ("short_searches", C.c_int32)]
 
 
 class NodeMeta(C.Structure):
@@ -70,7 +72,8 @@ class GameState(C.Structure):
                 ("hist_len", C.c_int32), ("free_top", C.c_int32), ("nleaves", C.c_int32),
                 ("leaf_base", C.c_int32), ("resign_disabled", C.c_int32), ("err", C.c_int32),
                 ("result", C.c_int32), ("was_resign", C.c_int32), ("nodes_used", C.c_int32),
-                ("short_first", C.c_int32), ("arena_k", C.c_int32), ("garbage", C.c_int32), ("pad", C.c_int32)]
+                ("short_first", C.c_int32), ("arena_k", C.c_int32), ("garbage", C.c_int32), ("npend", C.c_int32),
+                ("short_searches", C.c_int32), ("pad", C.c_int32)]
 
 
 class TreeArgs(C.Structure):
@@ -207,7 +210,7 @@ class Sim:
             self.L.hs_record_game(self.h, k, moves.ctypes.data_as(C.POINTER(C.c_int16)), pf(pis), pf(qs))
             out.append(dict(game_id=hd.game_id, num_moves=nm, result=hd.result, was_resign=hd.was_resign,
                             resign_disabled=hd.resign_disabled, final_score=hd.final_score,
-                            moves=moves[:nm].copy(), pis=pis[:nm].copy(), qs=qs[:nm].copy()))
+                            short_searches=hd.short_searches, moves=moves[:nm].copy(), pis=pis[:nm].copy(), qs=qs[:nm].copy()))
         return sorted(out, key=lambda r: r["game_id"])
 
     # ---- Go rules

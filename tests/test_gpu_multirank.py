@@ -198,3 +198,141 @@ def test_bench_eight_ranks_single_device_exchanges_sixteen_games_per_rank():
     assert "error" not in ex, ex
     assert ex["consistent"] and ex["games_in_arena"] == sum(ex["own_games_by_rank"])
     assert len(ex["own_games_by_rank"]) == 8 and min(ex["own_games_by_rank"]) >= 16, ex
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2 --single-device-test` with WORLD_SIZE unset (how the driver starts the N = 1 line): bench.py
+    is its own launcher -- two ranks, one JSON line from rank 0, per-rank rates and the exchange object (VERDICT r4 #1)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device-test", "--board", "5", "--tower", "1",
+           "--readouts", "16", "--games", "16", "--steps", "5", "--warmup", "2", "--stagger", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["scaling"] == "weak"
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1] and all(p["positions_per_s"] > 0 for p in d["per_rank"])
+    assert abs(sum(p["positions"] for p in d["per_rank"]) - d["positions"]) < 0.5
+    ex = d["exchange"]
+    assert "error" not in ex, ex
+    assert ex["consistent"] is True and ex["ms"] > 0 and ex["games_in_arena"] == sum(ex["own_games_by_rank"]) > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The real thing: RCCL, one rank per GPU, as many ranks as this box has devices (up to 8).  A 1-GPU box skips these; the
+# driver's multi-GPU box runs them without anyone asking.  Same checks as the gloo rehearsals above.
+
+def visible_devices():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def rccl_worker(rank, world, port, per_rank, q):
+    for p in (HERE, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+
+    import alphago_jl_amd as ag
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # carries the 128-byte RCCL id, nothing else
+    eng = ag.Engine(board_size=5, tower_height=1, games=4, num_readouts=16, seed=7, game_id_base=rank,
+                    game_id_stride=world, record_capacity_games=per_rank[rank] + 8, device=rank)
+    eng.init_synthetic(rank)                                              # every rank starts from DIFFERENT weights ...
+    ids = [ag.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    comm = eng.comm_create(rank, world, ids[0])
+    n = eng.broadcast_weights(comm, 0)                                    # ... and plays with rank 0's (ncclBroadcast)
+    out = {"rank": rank, "bcast": n,
+           "weights": hashlib.sha256(b"".join(np.ascontiguousarray(eng.get_weights(l, k), np.float32).tobytes()
+                                              for l, k in eng.layers())).hexdigest()}
+    if per_rank[rank] > 0:
+        eng.start(per_rank[rank])
+        while eng.records_count() < per_rank[rank]:
+            eng.step(8)
+    out["own"] = [digest(r) for r in eng.records()]
+    out["added"] = eng.allgather_records(comm)                            # ncclAllGather x 2, device to device
+    out["arena"] = [digest(eng.replay_record(k)) for k in range(eng.replay_count())]
+    out["positions"] = eng.replay_positions()
+    eng.records_clear()
+    out["again"] = eng.allgather_records(comm)
+    dist.barrier()
+    q.put(out)
+    eng.comm_destroy(comm)
+    eng.close()
+    dist.destroy_process_group()
+
+
+def run_rccl_world(per_rank):
+    import torch.multiprocessing as mp
+    world = len(per_rank)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=rccl_worker, args=(r, world, port, per_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        o = q.get(timeout=900)
+        got[o["rank"]] = o
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+def test_rccl_worker_with_a_world_of_one():
+    """the worker of the multi-GPU test below, on the one GPU every box has: its code path cannot rot unseen"""
+    got = run_rccl_world([3])
+    assert got[0]["added"] == 3 == len(got[0]["arena"]) and got[0]["again"] == 0 and got[0]["bcast"] > 0
+    assert sorted(got[0]["arena"]) == sorted(got[0]["own"])
+
+
+@pytest.mark.skipif(visible_devices() < 2, reason="RCCL refuses two ranks on one device: needs >= 2 visible GPUs")
+def test_rccl_exchange_and_broadcast_with_one_rank_per_visible_gpu():
+    """agz_comm_create + agz_broadcast_weights + agz_allgather_records over RCCL/xGMI with world = min(devices, 8): every
+    rank ends with rank 0's weights and with the same arena, rank order, equal to a single-rank engine's games of the same
+    ids (BASELINE configs[2]'s exchange; caller /root/reference/src/train.jl:56-66)"""
+    world = min(visible_devices(), 8)
+    per_rank = [5, 3, 4, 0, 6, 2, 3, 4][:world]
+    got = run_rccl_world(per_rank)
+    assert len({got[r]["weights"] for r in range(world)}) == 1 and all(got[r]["bcast"] > 0 for r in range(world))
+    arenas = [got[r]["arena"] for r in range(world)]
+    assert all(a == arenas[0] for a in arenas) and len(arenas[0]) == sum(per_rank)
+    assert [d[0] % world for d in arenas[0]] == [r for r, n in enumerate(per_rank) for _ in range(n)]
+    for r in range(world):
+        assert got[r]["added"] == sum(per_rank) and got[r]["again"] == 0 and got[r]["positions"] == got[0]["positions"]
+        assert sorted(d for d in arenas[0] if d[0] % world == r) == sorted(got[r]["own"])
+    import alphago_jl_amd as ag
+    single = ag.Engine(board_size=5, tower_height=1, games=4, num_readouts=16, seed=7, record_capacity_games=64, device=0)
+    single.init_synthetic(0)
+    want_ids = sorted(d[0] for d in arenas[0])
+    single.start(max(want_ids) + 1)
+    while single.records_count() < max(want_ids) + 1:
+        single.step(8)
+    want = {d[0]: d for d in (digest(r) for r in single.records())}
+    single.close()
+    assert all(d == want[d[0]] for d in arenas[0]), "a sharded game differs from the single-rank game with the same id"
+
+
+@pytest.mark.skipif(visible_devices() < 2, reason="needs >= 2 visible GPUs")
+def test_bench_self_launched_over_rccl_on_every_visible_gpu():
+    """`python bench.py --gpus W` (no launcher, no --single-device-test): W ranks on W GPUs, torch's nccl(=RCCL) group for
+    the scalars, libagz's own RCCL communicator for the replay exchange"""
+    world = min(visible_devices(), 8)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--board", "5", "--tower", "1",
+           "--readouts", "16", "--games", "16", "--steps", "20", "--warmup", "2", "--stagger", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and len(d["per_rank"]) == world and d["value"] > 0
+    ex = d["exchange"]
+    assert "error" not in ex, ex
+    assert ex["consistent"] and "ncclAllGather" in ex["collective"] and ex["games_in_arena"] == sum(ex["own_games_by_rank"])
