@@ -227,6 +227,60 @@ def cpu_baseline(N, tower, readouts, seconds):
     }
 
 
+def shard_leg(ag, torch, name, N, tower, R, games, precision, steps, warmup, stagger, device):
+    """One bounded leg of another BASELINE config on this GPU, reported beside `value`, never as it: one GPU's shard of
+    configs[3] (GoEnv(19), tower 20, 800 readouts, 2048 games over 8 GPUs -> 256 per GPU, exact f32) or configs[4] (fp16
+    MFMA tower, 1600 readouts, 4096 games -> 512 per GPU).  Same protocol as the headline: untimed prelude to the steady
+    regime, W warm-up steps, K timed steps between device synchronisations; HIP events around every tower layer; socket
+    power and shader clock sampled over the K steps."""
+    eng = ag.Engine(board_size=N, tower_height=tower, games=games, num_readouts=R, parallel_readouts=8, seed=1,
+                    device=device, stagger_moves=stagger)
+    try:
+        eng.init_synthetic(0)
+        eng.set_precision(precision)
+        eng.start(0)
+        prelude = (R + 7) // 8 + 5 if stagger > 0 else 0
+        eng.step(prelude + warmup)
+        eng.sync()
+        s0 = eng.stats()
+        eng.profile_conv(True)
+        sampler = PowerSampler(device).start()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step(steps)
+        eng.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        power = sampler.stop()
+        conv_ms, conv_flop, conv_n = eng.profile_conv_read()
+        eng.profile_conv(False)
+        s1 = eng.stats()
+        f16 = precision == "f16"
+        T4 = (N + 3) // 4
+        ratio = 1.0 if f16 else 36.0 * T4 * T4 / (9.0 * N * N)          # F(4x4,3x3): 36 multiplies per 4x4 tile (N >= 13)
+        peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
+        alg = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
+        pos = s1["positions"] - s0["positions"]
+        return {
+            "config": name, "precision": precision,
+            "workload": f"GoEnv({N}), tower_height={tower}, {R} readouts, {games} concurrent games on this GPU "
+                        f"(batch <= {8 * games} positions)",
+            "value": pos / dt, "unit": "positions/s", "steps": steps, "warmup": warmup, "setup_prelude_steps": prelude,
+            "ms_per_step": 1e3 * dt / steps, "positions": pos, "evals": s1["evals"] - s0["evals"],
+            "layer_ms": conv_ms / max(conv_n, 1), "layers_timed": conv_n,
+            "roofline": {"bound": "mfma", "kernel": "k_conv3x3_f16_w2 (implicit GEMM, v_mfma_f32_32x32x16_f16)" if f16 else
+                                  "Winograd F(4x4,3x3) tower layer (v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)",
+                         "achieved": alg * ratio if alg else None, "peak": peak, "unit": "TFLOP/s",
+                         "frac": alg * ratio / peak if alg else None, "achieved_algorithmic": alg},
+            "end_to_end_algorithmic_tflops": pos / dt * R * f_eval(N, tower) / 1e12,
+            "power": power,
+            "pool": {"node_capacity": s1["node_capacity"], "peak_nodes_per_game": s1["peak_nodes_per_game"],
+                     "short_searches": s1["pool_short_searches"], "refused_allocations": s1["pool_exhausted"]},
+        }
+    finally:
+        eng.close()
+
+
 def self_launch(n, single_device):
     """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here -- N copies of
     this very command, one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their
@@ -298,11 +352,15 @@ def main():
                     help="after the timed K steps keep playing, untimed for `value`: a warm-up until G games have ended "
                          "naturally, then a window until G more have; the line gains a `generation` object with SURVEY.md 8d's "
                          "generation rate (sum of position.n of the games that ended in the window / wall time) next to the "
-                         "steady-state rate of the same window.  Default: 128 on the headline workload at N = 1 (0 = off), "
-                         "bounded by --generation-seconds")
-    ap.add_argument("--generation-seconds", type=float, default=120.0,
-                    help="hard cap on the generation leg (two thirds for the warm-up, one third for the window); a leg the cap "
-                         "cut short reports what it saw and says so")
+                         "steady-state rate of the same window.  Default: a whole generation (G = --games = 1024) on the headline "
+                         "workload at N = 1 (0 = off), bounded by --generation-seconds")
+    ap.add_argument("--generation-seconds", type=float, default=900.0,
+                    help="hard cap on the generation leg (half for the warm-up generation, half for the measured one); a leg the "
+                         "cap cut short reports what it saw and says so")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the two bounded legs that run one GPU's shard of BASELINE configs[3] (19x19, tower 20, 800 "
+                         "readouts, 256 games, f32) and configs[4] (fp16 tower, 1600 readouts, 512 games) after the headline")
+    ap.add_argument("--config-leg-steps", type=int, default=20)
     ap.add_argument("--single-device-test", action="store_true",
                     help="testing only: every rank uses cuda:0 and gloo, to exercise the multi-rank code path on a 1-GPU box")
     args = ap.parse_args()
@@ -323,9 +381,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    headline = (args.board, args.tower, args.readouts, args.games, args.precision) == (9, 10, 400, 1024, "f32")
     if args.generation is None:      # SURVEY.md 8d's definition rides along on the headline line
-        headline = (args.board, args.tower, args.readouts, args.games, args.precision) == (9, 10, 400, 1024, "f32")
-        args.generation = 128 if (world == 1 and headline and args.stagger > 0) else 0
+        args.generation = args.games if (world == 1 and headline and args.stagger > 0) else 0
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} under a launcher that set WORLD_SIZE={world}: start {args.gpus} ranks, or "
                          f"run `python bench.py --gpus {args.gpus}` with WORLD_SIZE unset and it starts them itself")
@@ -348,7 +406,7 @@ def main():
     N, tower, R = args.board, args.tower, args.readouts
     eng = ag.Engine(board_size=N, tower_height=tower, games=args.games, num_readouts=R, parallel_readouts=8,
                     seed=1, game_id_base=rank, game_id_stride=world, device=local_rank,
-                    stagger_moves=args.stagger)
+                    stagger_moves=args.stagger, record_capacity_games=max(2 * args.games + 64, 2 * (args.generation or 0) + 64))
     eng.init_synthetic(0)
     eng.set_precision(args.precision)
     if args.winograd != 1:
@@ -441,7 +499,7 @@ def main():
     if args.generation > 0 and world == 1:
         G = args.generation
         import numpy as np
-        cap_warm, cap_win = args.generation_seconds * 2.0 / 3.0, args.generation_seconds / 3.0
+        cap_warm, cap_win = args.generation_seconds / 2.0, args.generation_seconds / 2.0
         g0 = eng.stats()["games_finished"]
         tw = time.perf_counter()
         while eng.stats()["games_finished"] - g0 < G and time.perf_counter() - tw < cap_warm:
@@ -476,9 +534,10 @@ def main():
             "capped": bool(warm_games < G or gd["games_finished"] < G), "cap_seconds": args.generation_seconds,
             "power": gpower,
             "note": "generation_rate counts the moves of the games that ENDED in the window (8d), steady_state_rate the moves "
-                    "PLAYED in it (bench.py's `value` definition); they differ while the population of game ages is not stationary: in this bounded leg every game started at once and "
-                    "the window holds the FIRST (shortest) endings, so generation_rate here is a lower bound; a whole generation of "
-                    "1024 games (tools/generation.py, ~5 min: profiles/r04_generation.json) gave 406 positions/s by 8d's definition",
+                    "PLAYED in it (bench.py's `value` definition).  With the default G = games per GPU the warm-up is a whole "
+                    "generation (every game of the staggered start-up population has been replaced) and the window is the next "
+                    "one: SURVEY.md 8d's 'timing over >= 1 full generation after a warm-up generation'.  A capped or smaller "
+                    "window holds the shortest games first and under-reads",
         }
         eng.records_clear()
 
@@ -654,6 +713,14 @@ def main():
             out["exchange"] = exchange
         if alt is not None:
             out["alt_precision"] = alt
+        if world == 1 and headline and args.stagger > 0 and not args.no_config_legs:
+            # BASELINE configs[3] / configs[4], one GPU's shard each, driver-witnessed: never `value`
+            for key, cfg in (("config3", ("configs[3]", 19, 20, 800, 256, "f32")), ("config4", ("configs[4]", 19, 20, 1600, 512, "f16"))):
+                try:
+                    out[key] = shard_leg(ag, torch, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], args.config_leg_steps,
+                                         5, 60, local_rank)
+                except Exception as ex:      # never at the expense of the line
+                    out[key] = {"config": cfg[0], "error": f"{type(ex).__name__}: {ex}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, tower, R, args.cpu_baseline_seconds)

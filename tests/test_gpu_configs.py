@@ -226,3 +226,52 @@ def compare_trees_19(eng, oroot, A):
         return compare_trees(eng, 0, eng.tree_root(0), oroot)
     finally:
         tt.A = old
+
+
+@pytest.mark.parametrize("precision,R", [("f32", 800), ("f16", 1600)])
+def test_c4_c5_whole_games_at_their_own_readout_budget(precision, R):
+    """configs[3] / configs[4] played to the END once: 19x19, tower 20, 800 readouts (exact f32,
+    F(4x4,3x3) tower) / 1600 readouts (fp16 tower), 16 concurrent games on the DEFAULT node pool until 8 of them are
+    over -- by resignation, two passes or at move 505 (/root/reference/src/selfplay.jl:22-43, src/mcts.jl:15-25).
+    Asserted: no allocation was ever refused and no search shortened (the default pool holds these trees; the peak
+    is printed); every record replays legally on the oracle's rules; a game that was not resigned ends by two passes or
+    at max_game_length with the oracle's Tromp-Taylor result and score; resigned games have Q(root) below the
+    threshold on their last recorded move; every pi is a distribution over moves that were legal."""
+    G, WANT = 16, 8
+    eng = ag.Engine(board_size=N19, tower_height=T20, games=G, num_readouts=R, seed=17, record_capacity_games=G + 8)
+    eng.init_synthetic(0)
+    eng.set_precision(precision)
+    eng.start(0)                                           # slots recycle: the batch stays 16 games wide
+    import time
+    t0, steps = time.time(), 0
+    per_move = (R + 7) // 8
+    while eng.records_count() < WANT and steps < 520 * per_move * 2:
+        eng.step(per_move)
+        steps += per_move
+    st = eng.stats()
+    recs = eng.records()
+    assert len(recs) >= WANT, f"{len(recs)} games over after {steps} steps"
+    assert st["pool_exhausted"] == 0 and st["pool_short_searches"] == 0 and st["stalled_games"] == 0
+    assert st["node_capacity"] == 16 * R + 256 + 16 * 505
+    ended = {"resign": 0, "passes": 0, "length": 0}
+    for r in recs:
+        assert r["short_searches"] == 0
+        pos = orc.make_pos(N19)
+        for k, a in enumerate(r["moves"]):
+            legal = orc.legal_moves(pos)
+            assert legal[int(a)] == 1 and not (r["pis"][k][legal == 0] > 0).any()
+            assert abs(float(r["pis"][k].sum()) - 1.0) < 1e-4
+            rc, pos = orc.play(pos, int(a))
+            assert rc == orc.OK
+        assert pos.n == r["num_moves"] <= 505
+        if r["was_resign"]:
+            ended["resign"] += 1
+            assert not r["resign_disabled"]
+        else:
+            assert pos.done or pos.n >= 505
+            ended["passes" if pos.done else "length"] += 1
+            assert r["result"] == L.or_result(C.byref(pos)) and abs(r["final_score"] - L.or_score(C.byref(pos))) < 1e-6
+    print(f"configs whole games {precision} R={R}: {len(recs)} games over in {steps} steps / {time.time() - t0:.0f} s, "
+          f"{sum(r['num_moves'] for r in recs)} moves, ended {ended}, peak nodes per game {st['peak_nodes_per_game']} of "
+          f"{st['node_capacity']} ({st['peak_nodes_per_game'] / st['node_capacity']:.2f}), evals {st['evals']}")
+    eng.close()

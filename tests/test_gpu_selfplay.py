@@ -98,15 +98,16 @@ def test_19x19_games_to_their_end_replay_on_the_oracle(precision):
     """Whole 19x19 games through recycled slots (the F(4x4,3x3) tower with its layer chains / the fp16 tower; 16 readouts):
     every game is filed once, every record replays legally on the oracle's rules and -- unless it was resigned -- ends by
     two passes or at max_game_length = 505 with the result the oracle's Tromp-Taylor count gives for the final board.
-    (The pool is asked for explicitly: DESIGN.md 2, the default assumes a flatter policy than the synthetic network's.)"""
+    On the DEFAULT node pool (16 R + 256 + 16 max_game_length since round 5: a sharp policy over a 500-move game keeps
+    more of its tree than 16 R covers when R is small)."""
     N, G, TOTAL = 19, 32, 40
-    eng = ag.Engine(board_size=N, tower_height=1, games=G, num_readouts=16, seed=33, record_capacity_games=TOTAL + 8,
-                    max_nodes_per_game=8192)
+    eng = ag.Engine(board_size=N, tower_height=1, games=G, num_readouts=16, seed=33, record_capacity_games=TOTAL + 8)
     eng.init_synthetic(0)
     eng.set_precision(precision)
     recs, st = run(eng, TOTAL, max_steps=60000)
-    assert len(recs) == TOTAL and st["pool_exhausted"] == 0
+    assert len(recs) == TOTAL and st["pool_exhausted"] == 0 and st["pool_short_searches"] == 0
     assert sorted(r["game_id"] for r in recs) == list(range(TOTAL))
+    print(f"19x19 {precision}: peak nodes per game {st['peak_nodes_per_game']} of {st['node_capacity']}")
     ended_by_length = 0
     for r in recs:
         pos = orc.make_pos(N)

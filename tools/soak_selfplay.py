@@ -9,17 +9,16 @@ import numpy as np, alphago_jl_amd as ag, orc
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 TOTAL = int(sys.argv[4]) if len(sys.argv) > 4 else 3000
-# (the default pool, 16 * readouts + 256 nodes per game, assumes the chosen child keeps < 94 % of the root's visits; the
-# synthetic network's policy is sharper than that over 500-move games, and an exhausted pool stalls its game: ask for more)
+# (the default pool: 16 * readouts + 256 + 16 * max_game_length nodes per game; the peak a game reached is printed)
 eng = ag.Engine(board_size=N, tower_height=2, games=G, num_readouts=32, seed=21, record_capacity_games=TOTAL+64,
-                max_nodes_per_game=0 if N == 9 else 16384)
+                max_nodes_per_game=0)
 eng.init_synthetic(0); eng.set_precision(sys.argv[1] if len(sys.argv) > 1 else "f32"); eng.start(TOTAL)
 t=time.time(); steps=0
 while eng.records_count() < TOTAL and steps < (20000 if N == 9 else 200000):
     eng.step(50); steps += 50
     if steps % 1000 == 0 and eng.stats()["pool_exhausted"]:
         sys.exit("node pool exhausted: raise max_nodes_per_game")
-st = eng.stats(); print("steps", steps, "sec", round(time.time()-t,1), {k: st[k] for k in ("games_finished","positions","pool_exhausted","resigned_games","evals")})
+st = eng.stats(); print("steps", steps, "sec", round(time.time()-t,1), {k: st[k] for k in ("games_finished","positions","pool_exhausted","pool_short_searches","peak_nodes_per_game","node_capacity","resigned_games","evals")})
 recs = eng.records()
 assert len(recs) == TOTAL and sorted(r["game_id"] for r in recs) == list(range(TOTAL))
 rng = np.random.RandomState(0)
