@@ -210,24 +210,20 @@ int64_t comm_allgather_records(Engine& E, Comm* c) {
   return E.replay_ingest_chunks(c->d_recv.p, coff, cbytes, cnrec);
 }
 
-// rank `root`'s parameters overwrite every other rank's replica (one flat f32 broadcast, 12-24 M parameters)
+// rank `root`'s parameters overwrite every other rank's replica: ONE ncclBroadcast of the network's device master
+// (Net::flux_device: every parameter as one flat f32 array, 12-24 M floats) in place, device to device.  The receivers'
+// inference images are rebuilt from it by kernels before their next forward; nothing is staged through the host
+// (round 4 went H2D -> broadcast -> D2H -> host repack: 476 ms at 19x19 / tower 20).
 int64_t comm_broadcast_weights(Engine& E, Comm* c, int root) {
   AGZ_REQUIRE(c != nullptr, AGZ_BAD_ARGUMENT, "null communicator");
   AGZ_REQUIRE(c->engine == &E, AGZ_BAD_ARGUMENT, "communicator belongs to another engine");
   AGZ_REQUIRE(root >= 0 && root < c->world, AGZ_BAD_ARGUMENT, "root %d of %d", root, c->world);
   hipStream_t s = E.stream();
-  std::vector<float> w = E.weights_flat();
-  DevBuf<float> d;
-  d.alloc(w.size());
-  if (c->rank == root) AGZ_HIP(hipMemcpyAsync(d.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice, s));
-  AGZ_RCCL(rccl().Broadcast(d.p, d.p, w.size(), ncclFloat32, root, c->comm, s));
-  if (c->rank != root) {
-    AGZ_HIP(hipMemcpyAsync(w.data(), d.p, sizeof(float) * w.size(), hipMemcpyDeviceToHost, s));
-    AGZ_HIP(hipStreamSynchronize(s));
-    E.weights_set_flat(w);
-  }
+  Net& net = E.net();
+  AGZ_RCCL(rccl().Broadcast(net.flux_device(), net.flux_device(), net.flux_count(), ncclFloat32, root, c->comm, s));
+  if (c->rank != root) net.device_master_written();
   AGZ_HIP(hipStreamSynchronize(s));
-  return (int64_t)w.size();
+  return (int64_t)net.flux_count();
 }
 
 }  // namespace agz

@@ -35,22 +35,8 @@ constexpr int HCH = kC / HK;       // 8 chunks
 
 static size_t conv16_weight_halves() { return (size_t)HCH * 9 * kC * HK; }
 
-// Wh[chunk][tap][cout][32]; tap reads x[row + da, col + db] with da = tap % 3 - 1, db = tap / 3 - 1 and
-// multiplies Flux's w[a = 1 - da, b = 1 - db] (NNlib true convolution), as in pack_conv3 (agz_nn.hip)
-static void conv16_pack_weights(const ConvHost& c, uint16_t* out) {
-  for (int cc = 0; cc < HCH; ++cc)
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) {
-        const int tap = (2 - a) + 3 * (2 - b);
-        for (int o = 0; o < kC; ++o)
-          for (int k = 0; k < HK; ++k) {
-            const int ci = cc * HK + k;
-            const __half h = __float2half_rn(c.w[a + 3 * (b + 3 * (ci + (size_t)kC * o))]);
-            out[(((size_t)cc * 9 + tap) * kC + o) * HK + k] = *reinterpret_cast<const uint16_t*>(&h);
-          }
-      }
-}
-
+// tap reads x[row + da, col + db] with da = tap % 3 - 1, db = tap / 3 - 1 and multiplies Flux's w[a = 1 - da, b = 1 - db]
+// (NNlib true convolution), as in pack_conv3 (agz_nn.hip)
 
 // uniform base in SGPRs + per-lane 32-bit byte offset
 __device__ __forceinline__ void glds16hs(const void* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_addr) {
@@ -102,17 +88,32 @@ constexpr int W2_RR = 2;                            // epilogue passes of residu
 
 size_t conv16_image_halves() { return conv16_weight_halves(); }
 
-// Wf[k-step 144][cout block 8][lane 64][8 halves]: the A operand of D = W . X^T in register order
+// Wf[k-step 144][cout block 8][lane 64][8 halves]: the A operand of D = W . X^T in register order.  Element `idx` of the
+// image straight from the Flux tensor (same source for the host reference and the device kernel).
+__host__ __device__ inline uint16_t conv16_image_element(const float* w, size_t idx) {
+  const int k = (int)(idx & 7), lane = (int)((idx >> 3) & 63), cb = (int)((idx >> 9) & 7), ks = (int)((idx >> 12) & 1);
+  const int st = (int)(idx >> 13);                                 // chunk * 9 + tap
+  const int cc = st / 9, tap = st % 9, a = 2 - tap % 3, b = 2 - tap / 3;
+  const int o = cb * 32 + (lane & 31), ci = cc * HK + (ks * 2 + (lane >> 5)) * 8 + k;
+  const _Float16 h = (_Float16)w[a + 3 * (b + 3 * (ci + (size_t)kC * o))];          // round to nearest even, as __float2half_rn
+  return *reinterpret_cast<const uint16_t*>(&h);
+}
 void conv16_pack_images(const ConvHost& c, uint16_t* out) {
-  std::vector<uint16_t> w(conv16_weight_halves());
-  conv16_pack_weights(c, w.data());
-  for (int st = 0; st < HCH * 9; ++st)
-    for (int ks = 0; ks < 2; ++ks)
-      for (int cb = 0; cb < 8; ++cb)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int k = 0; k < 8; ++k)
-            out[((((size_t)st * 2 + ks) * 8 + cb) * 64 + lane) * 8 + k] =
-                w[((size_t)st * kC + cb * 32 + (lane & 31)) * HK + (ks * 2 + (lane >> 5)) * 8 + k];
+  const size_t n = conv16_weight_halves();
+  for (size_t i = 0; i < n; ++i) out[i] = conv16_image_element(c.w.data(), i);
+}
+__global__ __launch_bounds__(256) void k_conv16_pack(const float* __restrict__ w, long wstride, int layers, uint16_t* __restrict__ out,
+                                                     long per) {
+  const long n = (long)layers * per;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+    const long l = t / per;
+    out[t] = conv16_image_element(w + l * wstride, (size_t)(t - l * per));
+  }
+}
+void launch_conv16_pack(const float* d_w, long wstride, int layers, uint16_t* d_out, hipStream_t s) {
+  const long per = (long)conv16_weight_halves();
+  const int grid = (int)std::min<long>((layers * per + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_conv16_pack, dim3(grid), dim3(256), 0, s, d_w, wstride, layers, d_out, per);
 }
 
 #ifdef AGZ_TIMING_EXPERIMENTS

@@ -909,19 +909,10 @@ void Engine::train_reset() {
   if (tr) tr->reset();
 }
 
-// every parameter of the selected network as one flat vector, in a fixed (layer, kind) order
-static void weight_keys(int tower, std::vector<std::pair<int, int>>& keys) {
-  for (int l = 0; l <= 2 * tower; ++l)
-    for (int k = 0; k < 7; ++k) keys.push_back({l, k});
-  for (int l : {AGZ_L_VALUE_CONV, AGZ_L_POLICY_CONV})
-    for (int k = 0; k < 7; ++k) keys.push_back({l, k});
-  for (int l : {AGZ_L_VALUE_FC1, AGZ_L_VALUE_FC2, AGZ_L_POLICY_FC})
-    for (int k = 0; k < 2; ++k) keys.push_back({l, k});
-}
-
+// every parameter of the selected network as one flat vector, in the order of the device master (Net::weight_keys)
 std::vector<float> Engine::weights_flat() {
   std::vector<std::pair<int, int>> keys;
-  weight_keys(net().tower(), keys);
+  Net::weight_keys(net().tower(), keys);
   std::vector<float> w;
   for (auto& lk : keys) {
     const int64_t n = net().param_count(lk.first, lk.second);
@@ -934,7 +925,7 @@ std::vector<float> Engine::weights_flat() {
 
 void Engine::weights_set_flat(const std::vector<float>& w) {
   std::vector<std::pair<int, int>> keys;
-  weight_keys(net().tower(), keys);
+  Net::weight_keys(net().tower(), keys);
   size_t at = 0;
   for (auto& lk : keys) {
     const int64_t n = net().param_count(lk.first, lk.second);

@@ -41,6 +41,20 @@ class Net {
   void get(int layer, int kind, float* out, int64_t count) const;
   void init_synthetic(uint64_t seed);
 
+  // The MASTER copy of every parameter lives on the device: one flat f32 array in the Flux layouts of the C ABI, in
+  // weight_keys order (per conv layer: w, b, beta, gamma, mean, var, eps; then the head convs; then the dense layers'
+  // w, b).  agz_net_set_weights writes through to it; the trainer and agz_broadcast_weights write it directly
+  // (device_master_written) and every inference image -- direct, F(3x3,3x3), F(4x4,3x3), fp16, split, folded affines --
+  // is derived from it by kernels on the engine's stream: new weights reach the next forward without visiting the host
+  // (/root/reference/src/train.jl:67-74 changes the weights every iteration).  The host vectors below are a cache.
+  static void weight_keys(int tower, std::vector<std::pair<int, int>>& keys);
+  float* flux_device() { return d_flux_.p; }
+  size_t flux_count() const { return flux_n_; }
+  size_t flux_offset(int layer, int kind) const;
+  void device_master_written() { host_stale_ = true; derived_dirty_ = true; ++param_version_; }
+  // (test hook) words of the device images that differ from the host restatement of the same packs; -1 if `which` is unknown
+  long debug_pack_diff(int which);
+
   // Reserve activation workspace for up to `bcap` positions.
   void reserve(int bcap);
   // d_x32: [bcap*P][32] stem input (17 planes + zero pad) ; d_count: device int, number of
@@ -71,7 +85,7 @@ class Net {
   bool tower_persistent() const { return tower_persistent_; }
   // tower arithmetic: 0 = exact f32 (default), 1 = fp16 operands / f32 accumulate (agz_conv16.hip)
   // 2 = exact-f32 network with the Winograd operands carried as two f16 halves (agz_wino.hip, split form)
-  void set_precision(int p) { precision_ = p; dirty_ = dirty_ || p == 1 || p == 2; }
+  void set_precision(int p) { precision_ = p; }
   int precision() const { return precision_; }
 
   // what this board sustains on nothing but independent v_mfma_f32_32x32x2_f32 (one launch of ~10 ms after another for
@@ -86,18 +100,9 @@ class Net {
   const ConvHost* conv(int layer) const;
   DenseHost* dense(int layer);
   const DenseHost* dense(int layer) const;
-  void mark_dirty() { dirty_ = true; packed16_ = false; }
-  // The trainer keeps the master copy of the parameters on the device between steps; the host copies (and with them
-  // every inference pack) are refreshed lazily: whoever is about to read or write a host parameter calls sync_host()
-  // first.  param_version() moves whenever the host copies are written from outside (set, init_synthetic).
-  void set_host_sync(std::function<void()> f) { host_sync_ = std::move(f); }
-  void set_host_stale(bool stale) { host_stale_ = stale; }
-  void sync_host() const {
-    if (host_stale_ && host_sync_) {
-      host_stale_ = false;          // (first: the callback itself reads and writes host parameters)
-      host_sync_();
-    }
-  }
+  // the host vectors are refreshed lazily from the device master: whoever is about to read a host parameter calls
+  // sync_host() first.  param_version() moves whenever the master is written (set, init_synthetic, trainer, broadcast).
+  void sync_host() const;
   uint64_t param_version() const { return param_version_; }
 
   double flops_per_eval() const;         // BASELINE.md F_eval
@@ -111,16 +116,23 @@ class Net {
   ConvHost stem_, vconv_, pconv_;
   std::vector<ConvHost> tconv_;
   DenseHost vfc1_, vfc2_, pfc_;
-  bool dirty_ = true;
-  std::function<void()> host_sync_;
-  mutable bool host_stale_ = false;
+  struct FluxSlot { int layer, kind; size_t off, n; };
+  std::vector<FluxSlot> slots_;
+  size_t flux_n_ = 0;
+  DevBuf<float> d_flux_;
+  bool derived_dirty_ = true;          // the inference images are older than the device master
+  mutable bool host_stale_ = false;    // the host vectors are older than the device master
   uint64_t param_version_ = 0;
+  void upload_slot(const FluxSlot& s);
+  void upload_host_all();
+  const float* host_slot(const FluxSlot& s) const;
 
   // device-resident packed parameters
   DevBuf<float> d_wstem_, d_wtower_;      // [cout][9*cin_pad] per layer
   DevBuf<float> d_scale_, d_shift_;       // (1 + 2*tower) x 256
   DevBuf<float> d_head_;                  // head conv weights + affine
-  DevBuf<float> d_vfc1w_, d_vfc1b_, d_vfc2w_, d_vfc2b_, d_pfcw_, d_pfcb_;
+  const float *d_vfc1w_ = nullptr, *d_vfc1b_ = nullptr, *d_vfc2w_ = nullptr, *d_vfc2b_ = nullptr, *d_pfcw_ = nullptr,
+              *d_pfcb_ = nullptr;      // the dense layers, read in place in the master
   // workspace
   int bcap_ = 0;
   DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
@@ -170,8 +182,8 @@ class Trainer {
 
  private:
   struct Param;
-  void upload();
-  void download();            // device master copies -> host parameters (Net::sync_host)
+  void upload();              // the network's device master -> training layouts (device to device)
+  void publish(long M);       // training layouts + running statistics -> the network's device master
   uint64_t uploaded_version_ = ~0ull;
   Net& net_;
   hipStream_t stream_;
@@ -184,6 +196,9 @@ class Trainer {
   int n_optw_ = 0;
 };
 
+// `layers` Flux tensors [3][3][cin][256] on the device, wstride floats apart -> Wt[cout][tap][cin_pad] images (the direct
+// kernel's and the trainer's layout)
+void launch_pack_direct(const float* d_w, long wstride, int cin, int cin_pad, int layers, float* d_out, hipStream_t s);
 // the direct implicit-GEMM 3x3 convolution of agz_nn.hip (y = act(scale * conv + shift (+ res))), cin_pad = 32 or 256
 void launch_conv3x3_direct_taps(const float* x, const float* wt, const float* ones, const float* zeros, const float* shift,
                                 float* y, float* part, const int* d_count, int bcap, int N, int cin_pad, hipStream_t s);
@@ -193,7 +208,9 @@ void launch_conv3x3_direct(const float* x, const float* wt, const float* scale, 
 
 // Winograd F(3x3,3x3) tower convolution (agz_wino.hip)
 constexpr int kWinoStages = 64, kWinoStemStages = 8;   // K-loop stages (input channels / 4) of a tower layer / the stem
-void wino_pack_weights(const ConvHost& c, float* out, int ns = kWinoStages);
+void wino_pack_weights(const ConvHost& c, float* out, int ns = kWinoStages);          // host restatement (test reference)
+// the product: `layers` Flux tensors [3][3][cin][256] on the device, wstride floats apart -> `layers` U images
+void launch_wino_pack(const float* d_w, long wstride, int cin, int layers, float* d_out, int ns, bool split, hipStream_t s);
 size_t wino_weight_floats(int ns = kWinoStages);
 size_t wino_v_floats(int bcap, int T);
 // x -> V (the 25 transformed planes as GEMM stage images); needed in front of the first Winograd layer, and
@@ -226,7 +243,8 @@ float wino_split_descale();
 constexpr int kWino4Stages = 96;             // K-loop stages of a layer: six passes (transform rows) x 16 stages of 6 planes x 16 cin
 bool wino4_applies(int N);                   // N >= 13: fewer multiplies per output point than F(3x3,3x3)
 bool wino4_whole_boards(int N);              // tile blocks hold whole boards (N = 13..16); else dense blocks + fix-up transform
-void wino4_pack_weights(const ConvHost& c, float* out);
+void wino4_pack_weights(const ConvHost& c, float* out);                              // host restatement (test reference)
+void launch_wino4_pack(const float* d_w, long wstride, int layers, float* d_out, hipStream_t s);
 size_t wino4_weight_floats();
 size_t wino4_v_floats(int bcap, int N);
 // x -> V (all tiles), or with fixup only the tiles the previous GEMM's epilogue could not emit (dense blocks)
@@ -241,7 +259,8 @@ bool wino4_paired(int N);                    // five boards per two tile blocks 
 // (part / parts: the part-th of `parts` ranges of tile blocks, cut at board boundaries: ranges are independent layer chains)
 
 // fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged
-void conv16_pack_images(const ConvHost& c, uint16_t* out);
+void conv16_pack_images(const ConvHost& c, uint16_t* out);                           // host restatement (test reference)
+void launch_conv16_pack(const float* d_w, long wstride, int layers, uint16_t* d_out, hipStream_t s);
 size_t conv16_image_halves();
 void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale, const float* shift, const void* res,
                        int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s);

@@ -338,6 +338,8 @@ static void dense_init(DenseHost& d, int in, int out) {
   d.b.assign(out, 0.f);
 }
 
+static std::vector<float>* conv_field(ConvHost* c, int kind);
+
 Net::Net(int N, int tower, hipStream_t stream) : N_(N), P_(N * N), A_(N * N + 1), tower_(tower), stream_(stream) {
   conv_init(stem_, 3, kCinStem, kC);
   tconv_.resize(2 * tower);
@@ -347,6 +349,62 @@ Net::Net(int N, int tower, hipStream_t stream) : N_(N), P_(N * N), A_(N * N + 1)
   dense_init(vfc1_, P_, 256);
   dense_init(vfc2_, 256, 1);
   dense_init(pfc_, 2 * P_, A_);
+  std::vector<std::pair<int, int>> keys;
+  weight_keys(tower_, keys);
+  for (auto& lk : keys) {
+    const size_t n = (size_t)param_count(lk.first, lk.second);
+    slots_.push_back({lk.first, lk.second, flux_n_, n});
+    flux_n_ += n;
+  }
+  d_flux_.alloc(flux_n_);
+  upload_host_all();
+}
+
+// every parameter in a fixed (layer, kind) order: the layout of the device master and of agz_broadcast_weights
+void Net::weight_keys(int tower, std::vector<std::pair<int, int>>& keys) {
+  for (int l = 0; l <= 2 * tower; ++l)
+    for (int k = 0; k < 7; ++k) keys.push_back({l, k});
+  for (int l : {AGZ_L_VALUE_CONV, AGZ_L_POLICY_CONV})
+    for (int k = 0; k < 7; ++k) keys.push_back({l, k});
+  for (int l : {AGZ_L_VALUE_FC1, AGZ_L_VALUE_FC2, AGZ_L_POLICY_FC})
+    for (int k = 0; k < 2; ++k) keys.push_back({l, k});
+}
+
+size_t Net::flux_offset(int layer, int kind) const {
+  for (const auto& sl : slots_)
+    if (sl.layer == layer && sl.kind == kind) return sl.off;
+  AGZ_REQUIRE(false, AGZ_BAD_ARGUMENT, "no parameter (layer %d, kind %d)", layer, kind);
+  return 0;
+}
+
+const float* Net::host_slot(const FluxSlot& sl) const {
+  if (const ConvHost* c = conv(sl.layer))
+    return sl.kind == AGZ_K_BN_EPS ? &c->eps : conv_field(const_cast<ConvHost*>(c), sl.kind)->data();
+  const DenseHost* d = dense(sl.layer);
+  return (sl.kind == AGZ_K_WEIGHT ? d->w : d->b).data();
+}
+
+// host vector -> its place in the device master (the host vectors never move: an enqueued copy may read them later)
+void Net::upload_slot(const FluxSlot& sl) {
+  AGZ_HIP(hipMemcpyAsync(d_flux_.p + sl.off, host_slot(sl), sizeof(float) * sl.n, hipMemcpyHostToDevice, stream_));
+}
+void Net::upload_host_all() {
+  std::vector<float> flat(flux_n_);
+  for (const auto& sl : slots_) std::memcpy(flat.data() + sl.off, host_slot(sl), sizeof(float) * sl.n);
+  AGZ_HIP(hipMemcpyAsync(d_flux_.p, flat.data(), sizeof(float) * flux_n_, hipMemcpyHostToDevice, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  derived_dirty_ = true;
+  host_stale_ = false;
+}
+
+// device master -> host vectors, when somebody other than agz_net_set_weights wrote the master
+void Net::sync_host() const {
+  if (!host_stale_) return;
+  std::vector<float> flat(flux_n_);
+  AGZ_HIP(hipMemcpyAsync(flat.data(), d_flux_.p, sizeof(float) * flux_n_, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  for (const auto& sl : slots_) std::memcpy(const_cast<float*>(host_slot(sl)), flat.data() + sl.off, sizeof(float) * sl.n);
+  host_stale_ = false;
 }
 
 ConvHost* Net::conv(int layer) {
@@ -405,7 +463,9 @@ void Net::set(int layer, int kind, const float* data, int64_t count) {
     DenseHost* d = dense(layer);
     std::memcpy((kind == AGZ_K_WEIGHT ? d->w : d->b).data(), data, sizeof(float) * (size_t)count);
   }
-  dirty_ = true;
+  for (const auto& sl : slots_)
+    if (sl.layer == layer && sl.kind == kind) upload_slot(sl);
+  derived_dirty_ = true;
 }
 
 void Net::get(int layer, int kind, float* out, int64_t count) const {
@@ -455,131 +515,216 @@ void Net::init_synthetic(uint64_t seed) {
   glorot(vfc1_.w, vfc1_.in, vfc1_.out, seed, AGZ_L_VALUE_FC1);
   glorot(vfc2_.w, vfc2_.in, vfc2_.out, seed, AGZ_L_VALUE_FC2);
   glorot(pfc_.w, pfc_.in, pfc_.out, seed, AGZ_L_POLICY_FC);
-  dirty_ = true;
+  upload_host_all();
 }
 
 // Flux [kw,kh,cin,cout] column-major -> Wt[cout][tap][cin_pad].  NNlib's conv is a TRUE
 // convolution: Flux index (a,b) multiplies x[i + 1 - a, j + 1 - b], i.e. tap offset
-// (da,db) = (1-a, 1-b); tap = (da+1) + 3*(db+1).
-static void pack_conv3(const ConvHost& c, int cin_pad, float* out) {
-  const int cin = c.cin, cout = c.cout;
-  std::memset(out, 0, sizeof(float) * (size_t)cout * 9 * cin_pad);
-  for (int o = 0; o < cout; ++o)
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) {
-        const int tap = (2 - a) + 3 * (2 - b);
-        for (int ci = 0; ci < cin; ++ci)
-          out[((size_t)o * 9 + tap) * cin_pad + ci] = c.w[a + 3 * (b + 3 * (ci + (size_t)cin * o))];
-      }
+// (da,db) = (1-a, 1-b); tap = (da+1) + 3*(db+1).  Element idx of the image (0 in the channel padding):
+__host__ __device__ inline float direct_image_element(const float* w, int cin, int cin_pad, size_t idx) {
+  const int ci = (int)(idx % cin_pad), tap = (int)((idx / cin_pad) % 9), o = (int)(idx / ((size_t)9 * cin_pad));
+  const int a = 2 - tap % 3, b = 2 - tap / 3;
+  return ci < cin ? w[a + 3 * (b + 3 * (ci + (size_t)cin * o))] : 0.f;
 }
-
-static void bn_affine(const ConvHost& c, float* scale, float* shift) {
-  for (int o = 0; o < c.cout; ++o) {
-    const double s = (double)c.gamma[o] / std::sqrt((double)c.var[o] + (double)c.eps);
-    scale[o] = (float)s;
-    shift[o] = (float)((double)c.beta[o] + s * ((double)c.b[o] - (double)c.mean[o]));
+static void pack_conv3(const ConvHost& c, int cin_pad, float* out) {          // host restatement (test reference)
+  const size_t n = (size_t)c.cout * 9 * cin_pad;
+  for (size_t i = 0; i < n; ++i) out[i] = direct_image_element(c.w.data(), c.cin, cin_pad, i);
+}
+__global__ __launch_bounds__(256) void k_pack_direct(const float* __restrict__ w, long wstride, int cin, int cin_pad, int layers,
+                                                     float* __restrict__ out) {
+  const long per = (long)kC * 9 * cin_pad, n = per * layers;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+    const long l = t / per;
+    out[t] = direct_image_element(w + l * wstride, cin, cin_pad, (size_t)(t - l * per));
   }
 }
 
+void launch_pack_direct(const float* d_w, long wstride, int cin, int cin_pad, int layers, float* d_out, hipStream_t s) {
+  const long n = (long)kC * 9 * cin_pad * layers;
+  hipLaunchKernelGGL(k_pack_direct, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, d_w, wstride, cin, cin_pad,
+                     layers, d_out);
+}
+
+// inference BatchNorm folded into the convolution: y = scale * conv + shift, in float64, rounded once
+__host__ __device__ inline void bn_affine_one(float gamma, float var, float eps, float beta, float b, float mean, float* scale,
+                                              float* shift) {
+#pragma clang fp contract(off)
+  const double s = (double)gamma / sqrt((double)var + (double)eps);
+  *scale = (float)s;
+  *shift = (float)((double)beta + s * ((double)b - (double)mean));
+}
+static void bn_affine(const ConvHost& c, float* scale, float* shift) {        // host restatement (test reference)
+  for (int o = 0; o < c.cout; ++o) bn_affine_one(c.gamma[o], c.var[o], c.eps, c.beta[o], c.b[o], c.mean[o], scale + o, shift + o);
+}
+// conv layer l of a run of `layers` whose small parameters sit `stride` floats apart behind `base` (= the layer's bias: the
+// master's order is w, b, beta, gamma, mean, var, eps): scale / shift rows l, and optionally scale * mul into scale2
+__global__ __launch_bounds__(256) void k_bn_affine(const float* __restrict__ base, long stride, int layers, int cout,
+                                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ scale2,
+                                                   float mul) {
+  const int n = layers * cout;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+    const int l = t / cout, o = t % cout;
+    const float* q = base + l * stride;
+    float sc, sh;
+    bn_affine_one(q[2 * cout + o], q[4 * cout + o], q[5 * cout], q[cout + o], q[o], q[3 * cout + o], &sc, &sh);      // gamma, var, eps, beta, b, mean
+    scale[t] = sc;
+    shift[t] = sh;
+    if (scale2) scale2[t] = sc * mul;        // (a power of two: exact)
+  }
+}
+// d_head_[776]: value conv w [256], policy conv w [2][256] (Flux [1,1,cin,2] column-major: ci + cin * o), the two folded affines
+__global__ void k_pack_head(const float* __restrict__ vw, const float* __restrict__ pw, float* __restrict__ hp) {
+  const int c = threadIdx.x;
+  hp[c] = vw[c];
+  hp[256 + c] = pw[c];
+  hp[512 + c] = pw[kC + c];
+  if (c < 8) hp[768 + c] = 0.f;
+  __syncthreads();
+  if (c == 0) {
+    const float* q = vw + kC;            // b, beta, gamma, mean, var, eps of the 1-channel BN
+    bn_affine_one(q[2], q[4], q[5], q[1], q[0], q[3], hp + 768, hp + 769);
+    const float* r = pw + 2 * kC;        // b[2], beta[2], gamma[2], mean[2], var[2], eps
+    bn_affine_one(r[4], r[8], r[10], r[2], r[0], r[6], hp + 770, hp + 771);
+    bn_affine_one(r[5], r[9], r[10], r[3], r[1], r[7], hp + 772, hp + 773);
+  }
+}
+
+// Every inference image from the device master, by kernels on stream_: no host work, no synchronisation.  The optional
+// images (F(4x4,3x3), fp16, split) are built when the mode that reads them is first used, and again whenever the master changes.
 void Net::pack() {
-  sync_host();
-  if (precision_ == 2 && tower_ > 0 && (dirty_ || !packed_split_)) {
-    const size_t uper = wino_weight_floats();
-    std::vector<float> u(uper * 2 * tower_);
-    for (int l = 0; l < 2 * tower_; ++l) wino_pack_weights_split(tconv_[l], u.data() + uper * l);
-    d_uwino_s_.ensure(u.size());
-    AGZ_HIP(hipMemcpyAsync(d_uwino_s_.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    std::vector<float> sc((size_t)(2 * tower_ + 1) * kC), tmp(kC);
-    for (int l = 0; l <= 2 * tower_; ++l) {        // the stem's comes last
-      bn_affine(l < 2 * tower_ ? tconv_[l] : stem_, sc.data() + (size_t)l * kC, tmp.data());
-      for (int o = 0; o < kC; ++o) sc[(size_t)l * kC + o] *= wino_split_descale();        // a power of two: exact
-    }
-    std::vector<float> us(wino_weight_floats(kWinoStemStages));
-    wino_pack_weights_split(stem_, us.data(), kWinoStemStages);
-    d_ustem_s_.ensure(us.size());
-    AGZ_HIP(hipMemcpyAsync(d_ustem_s_.p, us.data(), us.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    d_scale_s_.ensure(sc.size());
-    AGZ_HIP(hipMemcpyAsync(d_scale_s_.p, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    AGZ_HIP(hipStreamSynchronize(stream_));
+  const int L = 1 + 2 * tower_;
+  const float* F = d_flux_.p;
+  const size_t w0 = flux_offset(0, AGZ_K_WEIGHT);
+  const size_t w1 = tower_ > 0 ? flux_offset(1, AGZ_K_WEIGHT) : 0;
+  const long tstride = tower_ > 1 ? (long)(flux_offset(2, AGZ_K_WEIGHT) - w1) : 0;      // tower layers are equally spaced
+  if (derived_dirty_) { packed4_ = packed16_ = packed_split_ = false; }
+  if (precision_ == 2 && tower_ > 0 && !packed_split_) {
+    d_uwino_s_.ensure(wino_weight_floats() * 2 * tower_);
+    launch_wino_pack(F + w1, tstride, kC, 2 * tower_, d_uwino_s_.p, kWinoStages, true, stream_);
+    d_ustem_s_.ensure(wino_weight_floats(kWinoStemStages));
+    launch_wino_pack(F + w0, 0, kCinStem, 1, d_ustem_s_.p, kWinoStemStages, true, stream_);
     packed_split_ = true;
   }
-  if (use_wino4() && (dirty_ || !packed4_)) {
-    const size_t per4 = wino4_weight_floats();
-    std::vector<float> u(per4 * 2 * tower_);
-    for (int l = 0; l < 2 * tower_; ++l) wino4_pack_weights(tconv_[l], u.data() + per4 * l);
-    d_uwino4_.ensure(u.size());
-    AGZ_HIP(hipMemcpyAsync(d_uwino4_.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    AGZ_HIP(hipStreamSynchronize(stream_));
+  if (use_wino4() && !packed4_) {
+    d_uwino4_.ensure(wino4_weight_floats() * 2 * tower_);
+    launch_wino4_pack(F + w1, tstride, 2 * tower_, d_uwino4_.p, stream_);
     packed4_ = true;
   }
-  if (!dirty_ && (precision_ != 1 || packed16_)) return;
-  if (precision_ == 1 && tower_ > 0 && (dirty_ || !packed16_)) {
-    const size_t iper = conv16_image_halves();
-    std::vector<uint16_t> wi(iper * 2 * tower_);
-    for (int l = 0; l < 2 * tower_; ++l) conv16_pack_images(tconv_[l], wi.data() + iper * l);
-    d_wi16_.ensure(wi.size());
-    AGZ_HIP(hipMemcpyAsync(d_wi16_.p, wi.data(), wi.size() * sizeof(uint16_t), hipMemcpyHostToDevice, stream_));
-    AGZ_HIP(hipStreamSynchronize(stream_));
+  if (precision_ == 1 && tower_ > 0 && !packed16_) {
+    d_wi16_.ensure(conv16_image_halves() * 2 * tower_);
+    launch_conv16_pack(F + w1, tstride, 2 * tower_, d_wi16_.p, stream_);
     packed16_ = true;
   }
-  if (!dirty_) return;
-  if (precision_ != 1) packed16_ = false;
-  if (precision_ != 2) packed_split_ = false;
-  if (!use_wino4()) packed4_ = false;
-  const int L = 1 + 2 * tower_;
-  std::vector<float> scale((size_t)L * kC), shift((size_t)L * kC);
-  {
-    std::vector<float> w((size_t)kC * 9 * kCinStemPad);
-    pack_conv3(stem_, kCinStemPad, w.data());
-    d_wstem_.ensure(w.size());
-    AGZ_HIP(hipMemcpyAsync(d_wstem_.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    AGZ_HIP(hipStreamSynchronize(stream_));
-    bn_affine(stem_, scale.data(), shift.data());
-  }
+  if (!derived_dirty_) return;
+  d_wstem_.ensure((size_t)kC * 9 * kCinStemPad);
+  launch_pack_direct(F + w0, 0, kCinStem, kCinStemPad, 1, d_wstem_.p, stream_);
+  d_scale_.ensure((size_t)L * kC);
+  d_shift_.ensure((size_t)L * kC);
+  d_scale_s_.ensure((size_t)L * kC);
+  // affines: stem row 0, tower layer l row l; the split form's scales (x 1 / (operand scales)) tower first, the stem's last
+  hipLaunchKernelGGL(k_bn_affine, dim3(1), dim3(256), 0, stream_, F + flux_offset(0, AGZ_K_BIAS), 0L, 1, kC, d_scale_.p, d_shift_.p,
+                     d_scale_s_.p + (size_t)2 * tower_ * kC, wino_split_descale());
   if (tower_ > 0) {
-    const size_t per = (size_t)kC * 9 * kC;
-    std::vector<float> w(per * 2 * tower_);
-    for (int l = 0; l < 2 * tower_; ++l) {
-      pack_conv3(tconv_[l], kC, w.data() + per * l);
-      bn_affine(tconv_[l], scale.data() + (size_t)(l + 1) * kC, shift.data() + (size_t)(l + 1) * kC);
-    }
-    d_wtower_.ensure(w.size());
-    AGZ_HIP(hipMemcpyAsync(d_wtower_.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    AGZ_HIP(hipStreamSynchronize(stream_));
-    const size_t uper = wino_weight_floats();
-    std::vector<float> u(uper * 2 * tower_);
-    for (int l = 0; l < 2 * tower_; ++l) wino_pack_weights(tconv_[l], u.data() + uper * l);
-    d_uwino_.ensure(u.size());
-    AGZ_HIP(hipMemcpyAsync(d_uwino_.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    std::vector<float> us(wino_weight_floats(kWinoStemStages));
-    wino_pack_weights(stem_, us.data(), kWinoStemStages);
-    d_ustem_.ensure(us.size());
-    AGZ_HIP(hipMemcpyAsync(d_ustem_.p, us.data(), us.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-    AGZ_HIP(hipStreamSynchronize(stream_));
+    hipLaunchKernelGGL(k_bn_affine, dim3(2 * tower_), dim3(256), 0, stream_, F + flux_offset(1, AGZ_K_BIAS), tstride, 2 * tower_, kC,
+                       d_scale_.p + kC, d_shift_.p + kC, d_scale_s_.p, wino_split_descale());
+    d_wtower_.ensure((size_t)kC * 9 * kC * 2 * tower_);
+    launch_pack_direct(F + w1, tstride, kC, kC, 2 * tower_, d_wtower_.p, stream_);
+    d_uwino_.ensure(wino_weight_floats() * 2 * tower_);
+    launch_wino_pack(F + w1, tstride, kC, 2 * tower_, d_uwino_.p, kWinoStages, false, stream_);
+    d_ustem_.ensure(wino_weight_floats(kWinoStemStages));
+    launch_wino_pack(F + w0, 0, kCinStem, 1, d_ustem_.p, kWinoStemStages, false, stream_);
   }
-  auto up = [&](DevBuf<float>& d, const std::vector<float>& h) {
-    d.ensure(h.size());
-    AGZ_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+  d_head_.ensure(776);
+  hipLaunchKernelGGL(k_pack_head, dim3(1), dim3(256), 0, stream_, F + flux_offset(AGZ_L_VALUE_CONV, AGZ_K_WEIGHT),
+                     F + flux_offset(AGZ_L_POLICY_CONV, AGZ_K_WEIGHT), d_head_.p);
+  // the dense layers are read where they are
+  d_vfc1w_ = F + flux_offset(AGZ_L_VALUE_FC1, AGZ_K_WEIGHT); d_vfc1b_ = F + flux_offset(AGZ_L_VALUE_FC1, AGZ_K_BIAS);
+  d_vfc2w_ = F + flux_offset(AGZ_L_VALUE_FC2, AGZ_K_WEIGHT); d_vfc2b_ = F + flux_offset(AGZ_L_VALUE_FC2, AGZ_K_BIAS);
+  d_pfcw_ = F + flux_offset(AGZ_L_POLICY_FC, AGZ_K_WEIGHT); d_pfcb_ = F + flux_offset(AGZ_L_POLICY_FC, AGZ_K_BIAS);
+  AGZ_HIP(hipGetLastError());
+  derived_dirty_ = false;
+}
+
+// (test hook, agz_debug_pack_diff) the device images against the host restatement of the same packs, word for word
+long Net::debug_pack_diff(int which) {
+  pack();
+  sync_host();
+  const int L = 1 + 2 * tower_;
+  auto diff = [&](const void* dev, const void* host, size_t bytes) {
+    std::vector<uint32_t> got((bytes + 3) / 4, 0);
+    AGZ_HIP(hipMemcpyAsync(got.data(), dev, bytes, hipMemcpyDeviceToHost, stream_));
     AGZ_HIP(hipStreamSynchronize(stream_));
+    const uint32_t* want = static_cast<const uint32_t*>(host);
+    long bad = 0;
+    for (size_t i = 0; i < bytes / 4; ++i) bad += got[i] != want[i];
+    return bad;
   };
-  up(d_scale_, scale);
-  up(d_shift_, shift);
-  std::vector<float> hp(776, 0.f);
-  for (int c = 0; c < kC; ++c) {
-    hp[c] = vconv_.w[c];                       // [1,1,cin,1]
-    hp[256 + c] = pconv_.w[c];                 // [1,1,cin,2] column-major: ci + cin*o
-    hp[512 + c] = pconv_.w[kC + c];
+  switch (which) {
+    case 0: {      // direct images (stem + tower)
+      std::vector<float> w((size_t)kC * 9 * kCinStemPad);
+      pack_conv3(stem_, kCinStemPad, w.data());
+      long bad = diff(d_wstem_.p, w.data(), w.size() * 4);
+      const size_t per = (size_t)kC * 9 * kC;
+      w.resize(per);
+      for (int l = 0; l < 2 * tower_; ++l) { pack_conv3(tconv_[l], kC, w.data()); bad += diff(d_wtower_.p + per * l, w.data(), per * 4); }
+      return bad;
+    }
+    case 1: {      // F(3x3,3x3) images (tower + stem)
+      long bad = 0;
+      std::vector<float> u(wino_weight_floats());
+      for (int l = 0; l < 2 * tower_; ++l) { wino_pack_weights(tconv_[l], u.data()); bad += diff(d_uwino_.p + u.size() * l, u.data(), u.size() * 4); }
+      if (tower_ > 0) {
+        std::vector<float> us(wino_weight_floats(kWinoStemStages));
+        wino_pack_weights(stem_, us.data(), kWinoStemStages);
+        bad += diff(d_ustem_.p, us.data(), us.size() * 4);
+      }
+      return bad;
+    }
+    case 2: {      // F(4x4,3x3) images
+      if (!use_wino4()) return 0;
+      long bad = 0;
+      std::vector<float> u(wino4_weight_floats());
+      for (int l = 0; l < 2 * tower_; ++l) { wino4_pack_weights(tconv_[l], u.data()); bad += diff(d_uwino4_.p + u.size() * l, u.data(), u.size() * 4); }
+      return bad;
+    }
+    case 3: {      // fp16 images (precision f16 selected)
+      if (precision_ != 1 || tower_ == 0) return 0;
+      long bad = 0;
+      std::vector<uint16_t> wi(conv16_image_halves());
+      for (int l = 0; l < 2 * tower_; ++l) { conv16_pack_images(tconv_[l], wi.data()); bad += diff(d_wi16_.p + wi.size() * l, wi.data(), wi.size() * 2); }
+      return bad;
+    }
+    case 4: {      // split images + scales (precision f32s selected)
+      if (precision_ != 2 || tower_ == 0) return 0;
+      long bad = 0;
+      std::vector<float> u(wino_weight_floats());
+      for (int l = 0; l < 2 * tower_; ++l) { wino_pack_weights_split(tconv_[l], u.data()); bad += diff(d_uwino_s_.p + u.size() * l, u.data(), u.size() * 4); }
+      std::vector<float> us(wino_weight_floats(kWinoStemStages));
+      wino_pack_weights_split(stem_, us.data(), kWinoStemStages);
+      bad += diff(d_ustem_s_.p, us.data(), us.size() * 4);
+      std::vector<float> sc((size_t)L * kC), tmp(kC);
+      for (int l = 0; l <= 2 * tower_; ++l) {
+        bn_affine(l < 2 * tower_ ? tconv_[l] : stem_, sc.data() + (size_t)l * kC, tmp.data());
+        for (int o = 0; o < kC; ++o) sc[(size_t)l * kC + o] *= wino_split_descale();
+      }
+      return bad + diff(d_scale_s_.p, sc.data(), sc.size() * 4);
+    }
+    case 5: {      // folded affines + head block
+      std::vector<float> scale((size_t)L * kC), shift((size_t)L * kC);
+      bn_affine(stem_, scale.data(), shift.data());
+      for (int l = 0; l < 2 * tower_; ++l) bn_affine(tconv_[l], scale.data() + (size_t)(l + 1) * kC, shift.data() + (size_t)(l + 1) * kC);
+      long bad = diff(d_scale_.p, scale.data(), scale.size() * 4) + diff(d_shift_.p, shift.data(), shift.size() * 4);
+      std::vector<float> hp(776, 0.f);
+      for (int c = 0; c < kC; ++c) { hp[c] = vconv_.w[c]; hp[256 + c] = pconv_.w[c]; hp[512 + c] = pconv_.w[kC + c]; }
+      float s[2], t[2];
+      bn_affine(vconv_, s, t);
+      hp[768] = s[0]; hp[769] = t[0];
+      bn_affine(pconv_, s, t);
+      hp[770] = s[0]; hp[771] = t[0]; hp[772] = s[1]; hp[773] = t[1];
+      return bad + diff(d_head_.p, hp.data(), hp.size() * 4);
+    }
+    default: return -1;
   }
-  float s[2], t[2];
-  bn_affine(vconv_, s, t);
-  hp[768] = s[0]; hp[769] = t[0];
-  bn_affine(pconv_, s, t);
-  hp[770] = s[0]; hp[771] = t[0]; hp[772] = s[1]; hp[773] = t[1];
-  up(d_head_, hp);
-  up(d_vfc1w_, vfc1_.w); up(d_vfc1b_, vfc1_.b);
-  up(d_vfc2w_, vfc2_.w); up(d_vfc2b_, vfc2_.b);
-  up(d_pfcw_, pfc_.w); up(d_pfcb_, pfc_.b);
-  dirty_ = false;
 }
 
 void Net::reserve(int bcap) {
@@ -898,8 +1043,8 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
                      d_ph_.p, d_count, P_);
   const size_t smem = sizeof(float) * (size_t)(3 * P_ + A_ + 4);
   hipLaunchKernelGGL(k_head_fc, dim3(bcap), dim3(256), smem, stream_, (const float*)d_vh_.p,
-                     (const float*)d_ph_.p, d_vfc1w_.p, d_vfc1b_.p, d_vfc2w_.p, d_vfc2b_.p, d_pfcw_.p,
-                     d_pfcb_.p, d_pi, d_v, d_count, P_, A_);
+                     (const float*)d_ph_.p, d_vfc1w_, d_vfc1b_, d_vfc2w_, d_vfc2b_, d_pfcw_,
+                     d_pfcb_, d_pi, d_v, d_count, P_, A_);
   if (prof_on_ && prof_fwd_ < kProfMax) prof_fwd_++;
   AGZ_HIP(hipGetLastError());
 }

@@ -406,10 +406,8 @@ struct Trainer::Param {
   size_t n = 0;
 };
 
-Trainer::Trainer(Net& net, hipStream_t s) : net_(net), stream_(s) {
-  net_.set_host_sync([this] { download(); });
-}
-Trainer::~Trainer() { net_.set_host_sync(nullptr); }
+Trainer::Trainer(Net& net, hipStream_t s) : net_(net), stream_(s) {}
+Trainer::~Trainer() {}
 
 // The epsilon of TRAINING-mode BatchNorm.  A checkpoint's epsilon is the one its inference statistics were folded
 // with (bson_weights stores 0 for the Flux <= 0.7 dumps the reference ships: their sigma already contains it), and
@@ -419,107 +417,114 @@ static inline float train_eps(float eps) { return eps > 1e-5f ? eps : 1e-5f; }
 
 void Trainer::reset() { have_vel_ = false; }
 
-// host parameters (Flux layouts) -> training layouts on the device.  Convolutions: Wt[cout][tap][cin_pad], the layout
-// of the forward kernel (true-convolution flip applied); everything else as it is.
+// Flux [3][3][cin][256] <- Wt[cout][tap][cin_pad]: the inverse of the direct image (agz_nn.hip: direct_image_element)
+__global__ __launch_bounds__(256) void k_unpack_direct(const float* __restrict__ wt, int cin, int cin_pad, float* __restrict__ w) {
+  const long n = (long)9 * cin * kC;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int a = (int)(i % 3), b = (int)((i / 3) % 3), ci = (int)((i / 9) % cin), o = (int)(i / ((long)9 * cin));
+    w[i] = wt[((long)o * 9 + (2 - a) + 3 * (2 - b)) * cin_pad + ci];
+  }
+}
+// Flux BatchNorm's running statistics: (1 - 0.1) old + 0.1 batch, the variance with the m / (m - 1) correction
+__global__ void k_running_stats(float* __restrict__ mean, float* __restrict__ var, const float* __restrict__ bmean,
+                                const float* __restrict__ bvar, int n, float corr) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  mean[o] = (1.f - kBnMomentum) * mean[o] + kBnMomentum * bmean[o];
+  var[o] = (1.f - kBnMomentum) * var[o] + kBnMomentum * bvar[o] * corr;
+}
+
+// The network's device master (Flux layouts, Net::flux_device) -> training layouts, device to device.  Convolutions:
+// Wt[cout][tap][cin_pad], the layout of the forward kernel (true-convolution flip applied); everything else as it is.
 void Trainer::upload() {
-  // the device copies are current unless somebody wrote the host parameters since the last step
+  // the training copies are current unless somebody else wrote the master since the last step
   if (!params_.empty() && uploaded_version_ == net_.param_version()) {
     if (!have_vel_)
       for (auto& p : params_) AGZ_HIP(hipMemsetAsync(p->vel.p, 0, sizeof(float) * p->n, stream_));
     have_vel_ = true;
     return;
   }
-  net_.sync_host();
+  net_.sync_host();             // (the BatchNorm epsilons are read from the host copies)
   uploaded_version_ = net_.param_version();
   const int t = net_.tower(), L = 1 + 2 * t;
   if (params_.empty())
     for (size_t i = 0; i < (size_t)4 * L + 8 + 6; ++i) params_.emplace_back(new Param);
-  // every array is enqueued, ONE synchronisation at the end (one per array was 4 L + 14 round trips);
-  // the repacked convolution weights live in `staged` until then
-  std::vector<std::vector<float>> staged;
-  staged.reserve((size_t)L);
-  auto put = [&](Param& p, const std::vector<float>& h) {
-    p.n = h.size();
-    p.theta.ensure(p.n);
-    p.grad.ensure(p.n);
-    if (p.vel.n < p.n) { p.vel.ensure(p.n); have_vel_ = false; }
-    AGZ_HIP(hipMemcpyAsync(p.theta.p, h.data(), sizeof(float) * p.n, hipMemcpyHostToDevice, stream_));
+  const float* F = net_.flux_device();
+  auto size = [&](Param& p, size_t n) {
+    p.n = n;
+    p.theta.ensure(n);
+    p.grad.ensure(n);
+    if (p.vel.n < n) { p.vel.ensure(n); have_vel_ = false; }
+  };
+  auto put = [&](Param& p, int layer, int kind) {
+    size(p, (size_t)net_.param_count(layer, kind));
+    AGZ_HIP(hipMemcpyAsync(p.theta.p, F + net_.flux_offset(layer, kind), sizeof(float) * p.n, hipMemcpyDeviceToDevice, stream_));
   };
   for (int l = 0; l < L; ++l) {
-    const ConvHost& c = *net_.conv(l);
-    const int cinp = l == 0 ? kCinStemPad : kC;
-    std::vector<float> w((size_t)kC * 9 * cinp, 0.f);
-    for (int o = 0; o < kC; ++o)
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b)
-          for (int ci = 0; ci < c.cin; ++ci)
-            w[((size_t)o * 9 + (2 - a) + 3 * (2 - b)) * cinp + ci] = c.w[a + 3 * (b + 3 * (ci + (size_t)c.cin * o))];
-    staged.push_back(std::move(w));
-    put(*params_[4 * l + 0], staged.back());
-    put(*params_[4 * l + 1], c.b);
-    put(*params_[4 * l + 2], c.gamma);
-    put(*params_[4 * l + 3], c.beta);
+    const int cin = l == 0 ? kCinStem : kC, cinp = l == 0 ? kCinStemPad : kC;
+    size(*params_[4 * l + 0], (size_t)kC * 9 * cinp);
+    launch_pack_direct(F + net_.flux_offset(l, AGZ_K_WEIGHT), 0, cin, cinp, 1, params_[4 * l + 0]->theta.p, stream_);
+    put(*params_[4 * l + 1], l, AGZ_K_BIAS);
+    put(*params_[4 * l + 2], l, AGZ_K_BN_GAMMA);
+    put(*params_[4 * l + 3], l, AGZ_K_BN_BETA);
   }
   size_t k = (size_t)4 * L;
   for (int l : {AGZ_L_VALUE_CONV, AGZ_L_POLICY_CONV}) {
-    const ConvHost& c = *net_.conv(l);
-    put(*params_[k++], c.w);            // [1,1,256,cout] column-major = w[ci + 256 o]
-    put(*params_[k++], c.b);
-    put(*params_[k++], c.gamma);
-    put(*params_[k++], c.beta);
+    put(*params_[k++], l, AGZ_K_WEIGHT);            // [1,1,256,cout] column-major = w[ci + 256 o]
+    put(*params_[k++], l, AGZ_K_BIAS);
+    put(*params_[k++], l, AGZ_K_BN_GAMMA);
+    put(*params_[k++], l, AGZ_K_BN_BETA);
   }
   for (int l : {AGZ_L_VALUE_FC1, AGZ_L_VALUE_FC2, AGZ_L_POLICY_FC}) {
-    const DenseHost& d = *net_.dense(l);
-    put(*params_[k++], d.w);
-    put(*params_[k++], d.b);
+    put(*params_[k++], l, AGZ_K_WEIGHT);
+    put(*params_[k++], l, AGZ_K_BIAS);
   }
   if (!have_vel_)
     for (auto& p : params_) AGZ_HIP(hipMemsetAsync(p->vel.p, 0, sizeof(float) * p->n, stream_));
   have_vel_ = true;
-  AGZ_HIP(hipStreamSynchronize(stream_));      // the host sources (`staged`, the ConvHost / DenseHost vectors) are free again
 }
 
-// the inverse of upload(), plus the running BatchNorm statistics; marks the inference packs dirty
-void Trainer::download() {
+// The inverse of upload() after a step, plus the running BatchNorm statistics (d_stats_: the step's batch statistics):
+// the updated parameters go back into the network's device master -- device to device, nothing visits the host -- and
+// the inference images are rebuilt from there before the next forward (Net::pack).
+void Trainer::publish(long M) {
   const int t = net_.tower(), L = 1 + 2 * t;
-  auto get = [&](Param& p, std::vector<float>& h) {
-    h.resize(p.n);
-    AGZ_HIP(hipMemcpyAsync(h.data(), p.theta.p, sizeof(float) * p.n, hipMemcpyDeviceToHost, stream_));
+  float* F = net_.flux_device();
+  auto back = [&](Param& p, int layer, int kind) {
+    AGZ_HIP(hipMemcpyAsync(F + net_.flux_offset(layer, kind), p.theta.p, sizeof(float) * p.n, hipMemcpyDeviceToDevice, stream_));
   };
-  // all copies in flight, one synchronisation, then the convolution weights back into Flux order
-  std::vector<std::vector<float>> wt((size_t)L);
+  const float corr = (float)((double)M / (double)(M - 1));
   for (int l = 0; l < L; ++l) {
-    ConvHost& c = *net_.conv(l);
-    get(*params_[4 * l + 0], wt[l]);
-    get(*params_[4 * l + 1], c.b);
-    get(*params_[4 * l + 2], c.gamma);
-    get(*params_[4 * l + 3], c.beta);
+    const int cin = l == 0 ? kCinStem : kC, cinp = l == 0 ? kCinStemPad : kC;
+    hipLaunchKernelGGL(k_unpack_direct, dim3(l == 0 ? 160 : 2304), dim3(256), 0, stream_, (const float*)params_[4 * l + 0]->theta.p, cin,
+                       cinp, F + net_.flux_offset(l, AGZ_K_WEIGHT));
+    back(*params_[4 * l + 1], l, AGZ_K_BIAS);
+    back(*params_[4 * l + 2], l, AGZ_K_BN_GAMMA);
+    back(*params_[4 * l + 3], l, AGZ_K_BN_BETA);
+    const float* st = d_stats_.p + (size_t)3 * kC * l;
+    hipLaunchKernelGGL(k_running_stats, dim3(1), dim3(256), 0, stream_, F + net_.flux_offset(l, AGZ_K_BN_MEAN),
+                       F + net_.flux_offset(l, AGZ_K_BN_VAR), st, st + kC, kC, corr);
   }
   size_t k = (size_t)4 * L;
+  const float* sh = d_stats_.p + (size_t)3 * kC * L;         // value head {mean, var, rstd}; policy head {mean[2], var[2], rstd[2]}
+  int hc = 0;
   for (int l : {AGZ_L_VALUE_CONV, AGZ_L_POLICY_CONV}) {
-    ConvHost& c = *net_.conv(l);
-    get(*params_[k++], c.w);
-    get(*params_[k++], c.b);
-    get(*params_[k++], c.gamma);
-    get(*params_[k++], c.beta);
+    back(*params_[k++], l, AGZ_K_WEIGHT);
+    back(*params_[k++], l, AGZ_K_BIAS);
+    back(*params_[k++], l, AGZ_K_BN_GAMMA);
+    back(*params_[k++], l, AGZ_K_BN_BETA);
+    const int n = hc == 0 ? 1 : 2;
+    hipLaunchKernelGGL(k_running_stats, dim3(1), dim3(64), 0, stream_, F + net_.flux_offset(l, AGZ_K_BN_MEAN),
+                       F + net_.flux_offset(l, AGZ_K_BN_VAR), sh + (hc == 0 ? 0 : 3), sh + (hc == 0 ? 1 : 5), n, corr);
+    ++hc;
   }
   for (int l : {AGZ_L_VALUE_FC1, AGZ_L_VALUE_FC2, AGZ_L_POLICY_FC}) {
-    DenseHost& d = *net_.dense(l);
-    get(*params_[k++], d.w);
-    get(*params_[k++], d.b);
+    back(*params_[k++], l, AGZ_K_WEIGHT);
+    back(*params_[k++], l, AGZ_K_BIAS);
   }
-  AGZ_HIP(hipStreamSynchronize(stream_));
-  for (int l = 0; l < L; ++l) {
-    ConvHost& c = *net_.conv(l);
-    const int cinp = l == 0 ? kCinStemPad : kC;
-    const std::vector<float>& w = wt[l];
-    for (int o = 0; o < kC; ++o)
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b)
-          for (int ci = 0; ci < c.cin; ++ci)
-            c.w[a + 3 * (b + 3 * (ci + (size_t)c.cin * o))] = w[((size_t)o * 9 + (2 - a) + 3 * (2 - b)) * cinp + ci];
-  }
-  net_.mark_dirty();
+  AGZ_HIP(hipGetLastError());
+  net_.device_master_written();                 // host copies stale, inference images stale
+  uploaded_version_ = net_.param_version();     // ... and the training copies are what was just published
 }
 
 void Trainer::step(const float* feats, const float* pi, const float* z, int B, bool is_device, float eta, float rho,
@@ -736,11 +741,9 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
   }
   hipLaunchKernelGGL(k_momentum_all, dim3(n_optw_), dim3(256), 0, s, reinterpret_cast<const OptArray*>(d_opta_.p),
                      reinterpret_cast<const OptWork*>(d_optw_.p), eta, rho, d_losses + 2);
+  publish(M);       // parameters and running statistics into the network's device master (enqueued behind the update)
   double hl[4];
   AGZ_HIP(hipMemcpyAsync(hl, d_losses, sizeof(hl), hipMemcpyDeviceToHost, s));
-  // batch statistics for the running-statistics update
-  std::vector<float> hst((size_t)3 * kC * L + 9);
-  AGZ_HIP(hipMemcpyAsync(hst.data(), d_stats_.p, sizeof(float) * hst.size(), hipMemcpyDeviceToHost, s));
   AGZ_HIP(hipGetLastError());
   AGZ_HIP(hipStreamSynchronize(s));
   if (losses_out) {
@@ -749,30 +752,6 @@ void Trainer::step(const float* feats, const float* pi, const float* z, int B, b
     losses_out[3] = (float)((double)kRegW * hl[2]);
     losses_out[0] = losses_out[1] + losses_out[2] + losses_out[3];
   }
-  std::vector<std::vector<float>> bm(L + 2), bv(L + 2);
-  for (int l = 0; l < L; ++l) {
-    bm[l].assign(hst.begin() + (size_t)3 * kC * l, hst.begin() + (size_t)3 * kC * l + kC);
-    bv[l].assign(hst.begin() + (size_t)3 * kC * l + kC, hst.begin() + (size_t)3 * kC * l + 2 * kC);
-  }
-  const size_t ho = (size_t)3 * kC * L;
-  bm[L] = {hst[ho + 0]};
-  bv[L] = {hst[ho + 1]};
-  bm[L + 1] = {hst[ho + 3], hst[ho + 4]};
-  bv[L + 1] = {hst[ho + 5], hst[ho + 6]};
-  // running statistics (Flux: (1 - 0.1) old + 0.1 batch, variance with the m / (m - 1) correction) live on the host:
-  // the trainer itself never reads them
-  auto running = [&](ConvHost& c, const std::vector<float>& mean, const std::vector<float>& var) {
-    for (int o = 0; o < c.cout; ++o) {
-      c.mean[o] = (1.f - kBnMomentum) * c.mean[o] + kBnMomentum * mean[o];
-      c.var[o] = (1.f - kBnMomentum) * c.var[o] + kBnMomentum * var[o] * (float)((double)M / (double)(M - 1));
-    }
-  };
-  for (int l = 0; l < L; ++l) running(*net_.conv(l), bm[l], bv[l]);
-  running(*net_.conv(AGZ_L_VALUE_CONV), bm[L], bv[L]);
-  running(*net_.conv(AGZ_L_POLICY_CONV), bm[L + 1], bv[L + 1]);
-  // the trained parameters stay on the device; host copies and inference packs catch up when somebody needs them
-  net_.set_host_stale(true);
-  net_.mark_dirty();
 }
 
 }  // namespace agz

@@ -944,55 +944,66 @@ __global__ void k_xcd_census(int* out) {
 // Flux [kw,kh,cin,cout] column-major -> stage images U[cout block][stage][plane][cout 64][8] with
 // U_xi = G k G^T computed in float64.  k is the CORRELATION kernel: NNlib's conv is a true
 // convolution, so tap (a', b') reading x[i + a' - 1, j + b' - 1] carries w[2 - a', 2 - b'].
-void wino_pack_weights(const ConvHost& c, float* out, int ns) {
-  static const double G[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6, -1.0 / 6, 1.0 / 6},
-                                 {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
-  const int cin = c.cin, cout = c.cout;
-  std::memset(out, 0, sizeof(float) * wino_weight_floats(ns));
-  for (int o = 0; o < cout; ++o)
-    for (int ci = 0; ci < cin; ++ci) {
-      double k[3][3];
+// One (cout, cin) pair = one call of wino_pack_pair: the host loop below (test reference, agz_debug_pack_diff) and the
+// device kernel (the product: weights never leave the GPU between a training step / a broadcast and the next forward)
+// run the same source with FP contraction off, and produce the same bits.
+template <bool SPLIT>
+__host__ __device__ inline void wino_pack_pair(const float* w, int cin, int o, int ci, int ns, float* out) {
+#pragma clang fp contract(off)
+  constexpr double G[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6, -1.0 / 6, 1.0 / 6},
+                              {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
+  double k[3][3];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) k[a][b] = w[(2 - a) + 3 * ((2 - b) + 3 * (ci + (size_t)cin * o))];
+  const int cb = o / WC, ol = o % WC, st = ci / WK, cl = ci % WK;
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) {
+      double u = 0.0;
       for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) k[a][b] = c.w[(2 - a) + 3 * ((2 - b) + 3 * (ci + (size_t)cin * o))];
-      const int cb = o / WC, ol = o % WC, st = ci / WK, cl = ci % WK;
-      for (int i = 0; i < 5; ++i)
-        for (int j = 0; j < 5; ++j) {
-          double u = 0.0;
-          for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) u += G[i][a] * k[a][b] * G[j][b];
-          const int xi = i * 5 + j;
-          const int pos = 2 * wino_pair_pos(ol, xi, cl >> 1) + (cl & 1);
-          out[(((size_t)cb * ns + st) * WPL + (xi >> 1)) * WC * 8 + (size_t)ol * 8 + pos] = (float)u;
-        }
+        for (int b = 0; b < 3; ++b) u += G[i][a] * k[a][b] * G[j][b];
+      const int xi = i * 5 + j;
+      if (SPLIT) {          // u' = 2^10 u as (hi, lo) halves, rows laid out by wino_v_off (block h = 0: hi, 1: lo)
+        _Float16* o16 = reinterpret_cast<_Float16*>(out);
+        _Float16 hi, lo;
+        split_half((float)(u * (double)kSplitU), hi, lo);
+        const size_t base = ((size_t)cb * ns + st) * B_STAGE;       // floats
+        o16[2 * (base + wino_v_off(xi, ol, 0)) + cl] = hi;
+        o16[2 * (base + wino_v_off(xi, ol, 1)) + cl] = lo;
+      } else {
+        const int pos = 2 * wino_pair_pos(ol, xi, cl >> 1) + (cl & 1);
+        out[(((size_t)cb * ns + st) * WPL + (xi >> 1)) * WC * 8 + (size_t)ol * 8 + pos] = (float)u;
+      }
     }
 }
 
-// the same in the split form: u' = 2^10 u as (hi, lo) halves, rows laid out by wino_v_off (block h = 0: hi, 1: lo)
-void wino_pack_weights_split(const ConvHost& c, float* out, int ns) {
-  static const double G[5][3] = {{0.5, 0.0, 0.0}, {0.5, 0.5, 0.5}, {1.0 / 6, -1.0 / 6, 1.0 / 6},
-                                 {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
-  const int cin = c.cin, cout = c.cout;
+void wino_pack_weights(const ConvHost& c, float* out, int ns) {
   std::memset(out, 0, sizeof(float) * wino_weight_floats(ns));
-  _Float16* o16 = reinterpret_cast<_Float16*>(out);
-  for (int o = 0; o < cout; ++o)
-    for (int ci = 0; ci < cin; ++ci) {
-      double k[3][3];
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) k[a][b] = c.w[(2 - a) + 3 * ((2 - b) + 3 * (ci + (size_t)cin * o))];
-      const int cb = o / WC, ol = o % WC, st = ci / WK, cl = ci % WK;
-      for (int i = 0; i < 5; ++i)
-        for (int j = 0; j < 5; ++j) {
-          double u = 0.0;
-          for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) u += G[i][a] * k[a][b] * G[j][b];
-          const int xi = i * 5 + j;
-          _Float16 hi, lo;
-          split_half((float)(u * (double)kSplitU), hi, lo);
-          const size_t base = ((size_t)cb * ns + st) * B_STAGE;       // floats
-          o16[2 * (base + wino_v_off(xi, ol, 0)) + cl] = hi;
-          o16[2 * (base + wino_v_off(xi, ol, 1)) + cl] = lo;
-        }
-    }
+  for (int o = 0; o < c.cout; ++o)
+    for (int ci = 0; ci < c.cin; ++ci) wino_pack_pair<false>(c.w.data(), c.cin, o, ci, ns, out);
+}
+void wino_pack_weights_split(const ConvHost& c, float* out, int ns) {
+  std::memset(out, 0, sizeof(float) * wino_weight_floats(ns));
+  for (int o = 0; o < c.cout; ++o)
+    for (int ci = 0; ci < c.cin; ++ci) wino_pack_pair<true>(c.w.data(), c.cin, o, ci, ns, out);
+}
+
+// the same images from Flux-layout weights that are already on the device (Net's master copy): `layers` consecutive
+// [3][3][cin][256] tensors, `wstride` floats apart, into `layers` images.  One thread per (layer, cout, cin).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, long wstride, int cin, int layers, int ns,
+                                                   float* __restrict__ out, long per) {
+  const long n = (long)layers * kC * cin;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+    const int ci = (int)(t % cin), o = (int)((t / cin) % kC), l = (int)(t / ((long)cin * kC));
+    wino_pack_pair<SPLIT>(w + l * wstride, cin, o, ci, ns, out + l * per);
+  }
+}
+void launch_wino_pack(const float* d_w, long wstride, int cin, int layers, float* d_out, int ns, bool split, hipStream_t s) {
+  const long per = (long)wino_weight_floats(ns);
+  AGZ_HIP(hipMemsetAsync(d_out, 0, sizeof(float) * (size_t)per * layers, s));      // (the stem's 17 channels fill 5 of 8 stages' rows)
+  const int grid = (int)std::min<long>(((long)layers * kC * cin + 255) / 256, 65536);
+  if (split) hipLaunchKernelGGL(k_wino_pack<true>, dim3(grid), dim3(256), 0, s, d_w, wstride, cin, layers, ns, d_out, per);
+  else hipLaunchKernelGGL(k_wino_pack<false>, dim3(grid), dim3(256), 0, s, d_w, wstride, cin, layers, ns, d_out, per);
 }
 float wino_split_descale() { return 1.f / (kSplitV * kSplitU); }
 

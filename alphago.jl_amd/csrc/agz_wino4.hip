@@ -679,30 +679,47 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
 
 // Flux [kw,kh,cin,cout] column-major -> U stage images [cout block 4][stage 96][unit 24][row 64][4], U = G k G^T in
 // float64.  k is the CORRELATION kernel (NNlib's conv is a true convolution: tap (a', b') carries w[2 - a', 2 - b']).
-void wino4_pack_weights(const ConvHost& c, float* out) {
-  static const double G[6][3] = {{0.25, 0.0, 0.0},         {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-  const int cin = c.cin, cout = c.cout;
-  AGZ_REQUIRE(cin == kC && cout == kC, AGZ_BAD_ARGUMENT, "F(4x4,3x3) pack: tower layers only (%d -> %d)", cin, cout);
-  std::memset(out, 0, sizeof(float) * wino4_weight_floats());
-  std::vector<int> row_of(W4C);
-  for (int r = 0; r < W4C; ++r) row_of[w4_cout_of_urow(r)] = r;
-  for (int o = 0; o < cout; ++o)
-    for (int ci = 0; ci < cin; ++ci) {
-      double k[3][3];
+// One (cout, cin) pair per call, same source on the host (test reference) and in the device kernel (the product).
+__host__ __device__ inline void wino4_pack_pair(const float* w, int o, int ci, float* out) {
+#pragma clang fp contract(off)
+  constexpr double G[6][3] = {{0.25, 0.0, 0.0},         {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                              {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  double k[3][3];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) k[a][b] = w[(2 - a) + 3 * ((2 - b) + 3 * (ci + (size_t)kC * o))];
+  int r = 0;                                          // the U row that holds this cout: the inverse of w4_cout_of_urow
+  for (int q = 0; q < W4C; ++q)
+    if (w4_cout_of_urow(q) == o % W4C) r = q;
+  const int cb = o / W4C, cg = ci / 4, cl = ci % 4;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double u = 0.0;
       for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) k[a][b] = c.w[(2 - a) + 3 * ((2 - b) + 3 * (ci + (size_t)cin * o))];
-      const int cb = o / W4C, r = row_of[o % W4C], cg = ci / 4, cl = ci % 4;
-      for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-          double u = 0.0;
-          for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) u += G[i][a] * k[a][b] * G[j][b];
-          int stage, unit;
-          w4_slot(i, j, cg, stage, unit);
-          out[(size_t)cb * W4BLOCK + (size_t)stage * W4HALF + (size_t)unit * W4UNIT + w4_off(r, cl >> 1) + (cl & 1)] = (float)u;
-        }
+        for (int b = 0; b < 3; ++b) u += G[i][a] * k[a][b] * G[j][b];
+      int stage, unit;
+      w4_slot(i, j, cg, stage, unit);
+      out[(size_t)cb * W4BLOCK + (size_t)stage * W4HALF + (size_t)unit * W4UNIT + w4_off(r, cl >> 1) + (cl & 1)] = (float)u;
     }
+}
+void wino4_pack_weights(const ConvHost& c, float* out) {
+  AGZ_REQUIRE(c.cin == kC && c.cout == kC, AGZ_BAD_ARGUMENT, "F(4x4,3x3) pack: tower layers only (%d -> %d)", c.cin, c.cout);
+  std::memset(out, 0, sizeof(float) * wino4_weight_floats());
+  for (int o = 0; o < kC; ++o)
+    for (int ci = 0; ci < kC; ++ci) wino4_pack_pair(c.w.data(), o, ci, out);
+}
+__global__ __launch_bounds__(256) void k_wino4_pack(const float* __restrict__ w, long wstride, int layers, float* __restrict__ out,
+                                                    long per) {
+  const long n = (long)layers * kC * kC;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+    const int ci = (int)(t % kC), o = (int)((t / kC) % kC), l = (int)(t / ((long)kC * kC));
+    wino4_pack_pair(w + l * wstride, o, ci, out + l * per);
+  }
+}
+// `layers` consecutive Flux-layout tower tensors on the device (wstride floats apart) -> `layers` U images
+void launch_wino4_pack(const float* d_w, long wstride, int layers, float* d_out, hipStream_t s) {
+  const long per = (long)wino4_weight_floats();
+  const int grid = (int)std::min<long>(((long)layers * kC * kC + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_wino4_pack, dim3(grid), dim3(256), 0, s, d_w, wstride, layers, d_out, per);     // (every word of an image is written)
 }
 
 size_t wino4_weight_floats() { return (size_t)(kC / W4C) * W4BLOCK; }

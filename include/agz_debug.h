@@ -43,6 +43,12 @@ agz_status agz_debug_live_record(agz_engine* e, int32_t g, int32_t k, uint64_t* 
  * independent v_mfma_f32_32x32x2_f32 from registers -- back-to-back ~10 ms launches for `millis` (50..5000), median of the
  * second half.  On an MI355X at its power limit: ~124, i.e. 0.79 of the nominal 157.3.  Synchronises. */
 agz_status agz_debug_mfma_sustained(agz_engine* e, int32_t millis, float* tflops_out);
+/* The inference weight images are built on the device from the device master copy of the parameters (DESIGN.md "weights").
+ * This hook rebuilds image family `which` on the HOST from the host copies (the round-1..4 pack code, kept as the
+ * reference) and counts the 32-bit words in which the device image differs: 0 = direct Wt, 1 = F(3x3,3x3) U (+ stem),
+ * 2 = F(4x4,3x3) U, 3 = fp16 images (precision f16 selected), 4 = split-operand U + scales (precision f32s selected),
+ * 5 = folded BatchNorm affines + head block.  -1 for an unknown family. */
+agz_status agz_debug_pack_diff(agz_engine* e, int32_t which, int64_t* mismatches_out);
 
 #ifdef __cplusplus
 }

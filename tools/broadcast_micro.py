@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""What the weight broadcast costs ("replace the host staging ... or state the measured ms"): a world of one
-rank on this GPU, real RCCL through the C ABI.  Times agz_broadcast_weights (flat pack on the host, H2D, ncclBroadcast,
-and on a receiver D2H + unpack) and the first forward after the parameters changed (every inference image rebuilt on the
-host and uploaded: Winograd U in float64, folded affines, ...)."""
+"""What new weights cost before the next forward (/root/reference/src/train.jl:67-74 changes the weights every
+iteration): a world of one rank on this GPU, real RCCL through the C ABI.  Times agz_broadcast_weights (round 5: one
+ncclBroadcast of the device master copy, in place), the first forward after one array was set through
+agz_net_set_weights, and the first forward after an agz_train_step -- in every case all inference images (direct,
+F(3x3,3x3) / F(4x4,3x3) U in float64, folded affines) are rebuilt by kernels from the device master."""
 import json
 import sys
 import time
@@ -31,8 +32,24 @@ for N, tower in ((9, 10), (19, 20)):
     t3 = time.perf_counter()
     eng.forward_features(feats)
     t4 = time.perf_counter()
+    rng = np.random.RandomState(0)
+    B = 8
+    pi = rng.dirichlet(np.full(N * N + 1, 0.3), size=B).astype(np.float32)
+    z = rng.choice([-1.0, 1.0], size=B).astype(np.float32)
+    eng.train_step(feats, pi, z)                   # (allocations, first-use packs of the trainer)
+    eng.forward_features(feats)
+    t5 = time.perf_counter()
+    eng.train_step(feats, pi, z)
+    t6 = time.perf_counter()
+    eng.forward_features(feats)
+    t7 = time.perf_counter()
+    t8 = time.perf_counter()
+    w_back = eng.get_weights(1, 0)                 # the host copies catch up only when somebody asks
+    t9 = time.perf_counter()
     out.append({"board": N, "tower": tower, "parameters": n, "MB": 4e-6 * n, "broadcast_ms_root_world1": 1e3 * (t1 - t0),
-                "first_forward_after_new_weights_ms": 1e3 * (t3 - t2), "forward_ms_warm": 1e3 * (t4 - t3)})
+                "first_forward_after_new_weights_ms": 1e3 * (t3 - t2), "forward_ms_warm": 1e3 * (t4 - t3),
+                "train_step_ms_B8": 1e3 * (t6 - t5), "first_forward_after_train_step_ms": 1e3 * (t7 - t6),
+                "first_get_weights_after_train_step_ms": 1e3 * (t9 - t8)})
     eng.comm_destroy(comm)
     eng.close()
 print(json.dumps(out))
