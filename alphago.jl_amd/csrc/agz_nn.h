@@ -256,6 +256,7 @@ void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale,
                        float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s, int part = 0,
                        int parts = 1, bool y_for_fixup_only = false);
 bool wino4_paired(int N);                    // five boards per two tile blocks (N = 17..19)
+void wino4_validate(int bcap, int N);        // throws if the batch's tile index / byte offsets leave 32 bits (before any launch)
 // (part / parts: the part-th of `parts` ranges of tile blocks, cut at board boundaries: ranges are independent layer chains)
 
 // fp16-operand tower convolution (agz_conv16.hip); x is half, res / y are float* or half* as flagged

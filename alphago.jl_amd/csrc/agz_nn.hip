@@ -816,9 +816,9 @@ bool Net::fork_chains(int parts) {
 
 void Net::join_chains(int parts, bool pt) {
   if (parts <= 1) return;
-  for (int i = 0; i + 1 < parts; ++i) {
-    AGZ_HIP(hipEventRecord(ev_join_[i], streamx_[i]));
-    AGZ_HIP(hipStreamWaitEvent(stream_, ev_join_[i], 0));
+  for (int i = 0; i + 1 < parts; ++i) {          // (never throws: it also runs while an exception is in flight)
+    (void)hipEventRecord(ev_join_[i], streamx_[i]);
+    (void)hipStreamWaitEvent(stream_, ev_join_[i], 0);
   }
   if (pt) {
     (void)hipEventRecord(prof_ev_[2 * prof_n_ + 1], stream_);
@@ -839,6 +839,7 @@ void Net::check_async_error() {
 
 void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi, float* d_v) {
   check_async_error();      // (whichever launch form this forward takes)
+  if (use_wino4()) wino4_validate(bcap, N_);      // before anything is enqueued
   pack();
   reserve(bcap);
   const int grid = conv_grid(bcap, P_);
@@ -922,6 +923,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         const long tblocks = ((long)bcap * ((N_ + 3) / 4) * ((N_ + 3) / 4) + 63) / 64;
         const int parts = (int)std::max<long>(1, std::min<long>(tower_streams_, tblocks / 256));
         const bool pt = fork_chains(parts);
+        try {                          // (a launcher that throws must not leave the side streams un-joined: ADVICE r4)
         for (int part = 0; part < parts; ++part) {
           hipStream_t st = part == 0 ? stream_ : streamx_[part - 1];
           float *pa = a, *pb = b, *vc = vcur, *vn = vnxt;
@@ -943,6 +945,10 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
             else { layer1(); layer2(); }
             std::swap(pa, pb);
           }
+        }
+        } catch (...) {
+          join_chains(parts, pt);
+          throw;
         }
         join_chains(parts, pt);
         if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
@@ -998,6 +1004,7 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       const long tblocks3 = ((long)bcap * ((N_ + 2) / 3) * ((N_ + 2) / 3) + 62) / 63;
       const int parts = dense ? 1 : (int)std::max<long>(1, std::min<long>(std::min(chains33, (int)kMaxTowerStreams), tblocks3 / 256));
       const bool pt = fork_chains(parts);
+      try {
       for (int part = 0; part < parts; ++part) {
         hipStream_t st = part == 0 ? stream_ : streamx_[part - 1];
         float *pa = a, *pb = b;
@@ -1018,6 +1025,10 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
           else { layer1(); layer2(); }
           std::swap(pa, pb);
         }
+      }
+      } catch (...) {
+        join_chains(parts, pt);
+        throw;
       }
       join_chains(parts, pt);
       if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b

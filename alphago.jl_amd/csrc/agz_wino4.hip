@@ -743,10 +743,16 @@ static void wino4_check(int bcap, int N) {
               "batch of %d positions at %dx%d: tile index / activation byte offset exceeds 32 bits", bcap, N, N);
 }
 
+void wino4_validate(int bcap, int N) { wino4_check(bcap, N); }
+
 // part / parts: this launch covers the part-th of `parts` equal ranges of tile blocks (cut at block-pair boundaries, so that
-// no board straddles two ranges: a range's layers depend on nothing outside it, and ranges can run on different streams)
-static void wino4_range(int blocks, int part, int parts, int& tb0, int& tb1) {
+// no board straddles two ranges: a range's layers depend on nothing outside it, and ranges can run on different streams).
+// An even block index is a board boundary only with whole-board (N = 13..16) or paired (N = 17..19) packing: dense
+// non-paired packing (T >= 6) must run as one range (unreachable while board_size <= 19).
+static void wino4_range(int blocks, int part, int parts, int& tb0, int& tb1, int T) {
   AGZ_REQUIRE(parts >= 1 && part >= 0 && part < parts, AGZ_BAD_ARGUMENT, "block range %d of %d", part, parts);
+  AGZ_REQUIRE(parts == 1 || w4_whole_boards(T) || w4_paired(T), AGZ_BAD_ARGUMENT,
+              "F(4x4,3x3): %d layer chains need whole-board or paired tile packing (T = %d packs densely)", parts, T);
   const int per = ((blocks + parts - 1) / parts + 1) & ~1;      // even: whole block pairs
   tb0 = std::min(blocks, part * per);
   tb1 = part + 1 == parts ? blocks : std::min(blocks, tb0 + per);
@@ -755,7 +761,7 @@ static void wino4_range(int blocks, int part, int parts, int& tb0, int& tb1) {
 void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, int N, hipStream_t s, bool fixup, int part, int parts) {
   const int T = (N + 3) / 4;
   int tb0, tb1;
-  wino4_range((int)wino4_blocks(bcap, T), part, parts, tb0, tb1);
+  wino4_range((int)wino4_blocks(bcap, T), part, parts, tb0, tb1, T);
   if (tb1 <= tb0) return;
   wino4_check(bcap, N);
   if (fixup) {
@@ -778,7 +784,7 @@ void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale,
                        float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s, int part, int parts, bool ypart) {
   const int T = (N + 3) / 4;
   int tb0, tb1;
-  wino4_range((int)wino4_blocks(bcap, T), part, parts, tb0, tb1);
+  wino4_range((int)wino4_blocks(bcap, T), part, parts, tb0, tb1, T);
   if (tb1 <= tb0) return;
   const int blocks = tb1 - tb0;
   const int per_xcd = 4 * ((blocks + 7) / 8);

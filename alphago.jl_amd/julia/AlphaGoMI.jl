@@ -23,7 +23,7 @@ export GoEnv, Position, NeuralNet, MCTSPlayer, selfplay, extract_data, initializ
        # the node-level surface test/test_mcts.jl:2-5 and test/test_mcts_player.jl:3-6 import
        MCTSNode, select_leaf, maybe_add_child!, add_virtual_loss!, revert_virtual_loss!,
        incorporate_results!, inject_noise!, child_action_score, child_Q, child_U, child_N, child_W,
-       child_prior, N, Q, set_N!, suggest_move, get_position
+       child_prior, N, Q, set_N!, suggest_move, get_position, children       # (`position` stays unexported: Base exports a function of that name; node.position and get_position serve)
 
 const libagz = get(ENV, "AGZ_LIB", joinpath(@__DIR__, "..", "libagz.so"))
 
@@ -388,7 +388,28 @@ struct MCTSNode
   id::Int32
 end
 Base.getproperty(p::MCTSPlayer, s::Symbol) = s === :root ? MCTSNode(p, root(p)) : getfield(p, s)
-Base.:(==)(a::MCTSNode, b::MCTSNode) = a.player === b.player && a.id == b.id
+Base.:(==)(a::MCTSNode, b::MCTSNode) = getfield(a, :player) === getfield(b, :player) && getfield(a, :id) == getfield(b, :id)
+# The reference's tests read a node's state as FIELDS (test/test_mcts.jl:52-70, test/test_mcts_player.jl:150-175:
+# node.position, .children, .child_N, .child_prior, .fmove, .parent, .is_expanded ...; src/mcts.jl:41-53): each is one
+# accessor call on the device tree (ADVICE r4).  `fmove` is 1-based as in the reference (nothing for a root); `parent`
+# is an MCTSNode (nothing for a root: the reference's DummyNode carries no state a test reads).
+function Base.getproperty(x::MCTSNode, s::Symbol)
+  (s === :player || s === :id) && return getfield(x, s)
+  s === :position && return position(x)
+  s === :children && return children(x)
+  s === :child_N && return child_N(x)
+  s === :child_W && return child_W(x)
+  s === :child_prior && return child_prior(x)
+  s === :original_prior && return child_prior(x)      # mcts.jl:49: equal until inject_noise! (the device keeps one row)
+  info = node_info(x)
+  s === :fmove && return info.fmove < 0 ? nothing : Int(info.fmove) + 1
+  s === :parent && return info.parent < 0 ? nothing : MCTSNode(getfield(x, :player), info.parent)
+  s === :is_expanded && return info.is_expanded != 0
+  s === :losses_applied && return Int(info.losses_applied)
+  error("MCTSNode has no field $s")
+end
+Base.propertynames(::MCTSNode) = (:player, :id, :position, :children, :child_N, :child_W, :child_prior, :original_prior,
+                                  :fmove, :parent, :is_expanded, :losses_applied)
 
 node_info(x::MCTSNode) = node_info(x.player, x.id)
 N(x::MCTSNode) = node_info(x).N                                                 # mcts.jl:98-100
@@ -481,6 +502,12 @@ function position(x::MCTSNode)                                                  
   pos.ko = info.pos.ko < 0 ? nothing : from_flat(info.pos.ko + 1, env)
   pos.to_play = info.pos.to_play
   pos.done = info.done != 0
+  # `recent`: the C ABI exposes the last two moves of a node (agz_position_info.last_move / prev_move: what select_leaf's
+  # pass rule and the double-pass end need, mcts.jl:119-126); the full move list of a game is extract_data's
+  # (agz_records_game).  `board_deltas` is not rebuilt here: features come from agz_features / the leaf feature call.
+  to_pm(a, color) = PlayerMove(color, a == env.N^2 ? nothing : from_flat(a + 1, env))
+  if info.pos.prev_move >= 0 push!(pos.recent, to_pm(Int(info.pos.prev_move), pos.to_play)) end
+  if info.pos.last_move >= 0 push!(pos.recent, to_pm(Int(info.pos.last_move), -pos.to_play)) end
   pos
 end
 
