@@ -137,7 +137,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // per CU, direct epilogue)
 // WL: the weight fragments reach the wave through a wave-private LDS ring filled by LDS-DMA (and the results leave through
 // the direct epilogue) instead of global_load -> registers + the trickled result image: see "Round 4" below.
-template <int DBG, int RES, bool OUTF, int RB, bool WL>
+// ZB (round 5, AGZ_C16_ZB=1): a lane whose neighbour is off the board reads its zeros from a 256-byte zero block at the
+// offset its real address has modulo 256 -- the same LDS banks as a lane that is on the board -- instead of from one shared
+// 64-byte zero row: the slab reads become conflict-free whatever the tile's share of edge points.
+template <int DBG, int RES, bool OUTF, int RB, bool WL, bool ZB>
 __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const void* __restrict__ res, void* __restrict__ y,
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   constexpr int W2_RB = RB, W2_HM = 32 * RB;
   constexpr int W2_SLABCH = ((W2_HM + 2 * 20) * 4 + 63) / 64, NPJ = (W2_SLABCH + 3) / 4;
   constexpr int W2_SLAB = W2_SLABCH * 512, W2_SLABS = W2_SLAB + 32;
-  constexpr int W2_OFF_SC = 2 * W2_SLABS, W2_OFF_OUT = W2_OFF_SC + 1024;
+  constexpr int W2_OFF_Z = (2 * W2_SLABS + 127) / 128 * 128;            // ZB: 128 halves of zeros, 256-byte aligned
+  constexpr int W2_OFF_SC = ZB ? W2_OFF_Z + 128 : 2 * W2_SLABS, W2_OFF_OUT = W2_OFF_SC + 1024;
   constexpr int TINB = RES == 0 ? 0 : (RESF ? 32 * 272 : 32 * 144), TOUTB = OUTF ? 32 * 272 : 32 * 144;   // direct epilogue tiles
   constexpr int W2_OUTB = TRICKLE ? 4 * RB * 4096 : 4 * (TINB + TOUTB);
   // WL: a ring of WD k-steps of this wave's two fragments (2 KB per k-step) in LDS; W2_D = how far ahead the fetch runs
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   constexpr int RSB = RESF ? 272 : 144, RPR = RESF ? 16 : 8, RNP = RESF ? 8 : 4;
   constexpr int OSB = OUTF ? 272 : 144, OPR = OUTF ? 16 : 8, ONP = OUTF ? 8 : 4;
   constexpr int NRR = RESF ? 1 : W2_RR;               // 8 uint4 of ring either way
-  __shared__ __attribute__((aligned(128))) _Float16 smem[W2_SMEM];
+  __shared__ __attribute__((aligned(256))) _Float16 smem[W2_SMEM];
   const int P = N * N;
   const int M = (*d_count) * P;                          // < 2^31: 8192 x 361 rows
   const int ntiles = (M + W2_HM - 1) / W2_HM;
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   const int nslabch = (slab * 4 + 63) / 64;
   char* sm = reinterpret_cast<char*>(smem);
   if (tid < 8) reinterpret_cast<uint4*>(smem + (tid >> 2) * W2_SLABS + W2_SLAB)[tid & 3] = make_uint4(0, 0, 0, 0);
+  if (ZB && tid < 16) reinterpret_cast<uint4*>(smem + W2_OFF_Z)[tid] = make_uint4(0, 0, 0, 0);
   {
     float* tab = reinterpret_cast<float*>(smem + W2_OFF_SC);
     tab[tid] = scale[tid];
@@ -222,10 +227,12 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   auto tap_addr = [&](int sbuf, int tapi) __attribute__((always_inline)) {
     const int off = (tapi % 3 - 1) + N * (tapi / 3 - 1);
     const int base = sbuf * (W2_SLABS * 2);
-    const int R0 = l31 + halo + off;
+    int R0 = l31 + halo + off;
+    if (ZB) asm volatile("" : "+v"(R0));      // (else hipcc hoists the 18 zero-block offsets of a tile out of the chunk loop and spills)
     const int a0 = base + (R0 << 6) + ((((R0 >> 2) ^ hi) & 3) << 4);      // row block rbk: + rbk * 2048, same swizzle
+    const int z0 = ZB ? W2_OFF_Z * 2 + (a0 & 255) : base + W2_SLAB * 2;      // (row blocks are 2048 bytes apart: same banks)
 #pragma unroll
-    for (int rbk = 0; rbk < W2_RB; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : base + W2_SLAB * 2;
+    for (int rbk = 0; rbk < W2_RB; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : z0;
   };
   // (one register set: a row block's fragment of the next k-step is fetched right after the block's two MFMAs)
   auto read_a = [&](int ks, int rbk) __attribute__((always_inline)) {
@@ -566,8 +573,16 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   if (!ncu) AGZ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
   const int rk = !res ? 0 : (res_f32 ? 2 : 1);
   const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
-#define AGZ_C16_W2(D, R, OF, RB, G) \
-  hipLaunchKernelGGL((k_conv3x3_f16_w2<D, R, OF, RB, AGZ_C16_WL>), dim3(G), dim3(256), 0, s, xh, wi, scale, shift, res, y, d_count, N, relu)
+  static const bool zb = getenv("AGZ_C16_ZB") && atoi(getenv("AGZ_C16_ZB")) != 0;
+#define AGZ_C16_W2(D, R, OF, RB, G)                                                                                                      \
+  do {                                                                                                                                   \
+    if (zb && (D) == 0)                                                                                                                  \
+      hipLaunchKernelGGL((k_conv3x3_f16_w2<0, R, OF, RB, AGZ_C16_WL, true>), dim3(G), dim3(256), 0, s, xh, wi, scale, shift, res, y,    \
+                         d_count, N, relu);                                                                                              \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((k_conv3x3_f16_w2<D, R, OF, RB, AGZ_C16_WL, false>), dim3(G), dim3(256), 0, s, xh, wi, scale, shift, res, y,   \
+                         d_count, N, relu);                                                                                              \
+  } while (0)
 #define AGZ_C16_W2D(D, RB, G)                          \
   do {                                                 \
     if (out_f32) {                                     \

@@ -596,7 +596,7 @@ void Net::pack() {
   const float* F = d_flux_.p;
   const size_t w0 = flux_offset(0, AGZ_K_WEIGHT);
   const size_t w1 = tower_ > 0 ? flux_offset(1, AGZ_K_WEIGHT) : 0;
-  const long tstride = tower_ > 1 ? (long)(flux_offset(2, AGZ_K_WEIGHT) - w1) : 0;      // tower layers are equally spaced
+  const long tstride = tower_ > 0 ? (long)(flux_offset(2, AGZ_K_WEIGHT) - w1) : 0;      // tower layers (2 per block) are equally spaced
   if (derived_dirty_) { packed4_ = packed16_ = packed_split_ = false; }
   if (precision_ == 2 && tower_ > 0 && !packed_split_) {
     d_uwino_s_.ensure(wino_weight_floats() * 2 * tower_);
