@@ -137,10 +137,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // per CU, direct epilogue)
 // WL: the weight fragments reach the wave through a wave-private LDS ring filled by LDS-DMA (and the results leave through
 // the direct epilogue) instead of global_load -> registers + the trickled result image: see "Round 4" below.
-// ZB (round 5, AGZ_C16_ZB=1): a lane whose neighbour is off the board reads its zeros from a 256-byte zero block at the
-// offset its real address has modulo 256 -- the same LDS banks as a lane that is on the board -- instead of from one shared
-// 64-byte zero row: the slab reads become conflict-free whatever the tile's share of edge points.
-template <int DBG, int RES, bool OUTF, int RB, bool WL, bool ZB>
+// DM (round 5, AGZ_C16_DM=1): a lane whose neighbour is off the board reads the slab like every other lane -- the address
+// it computes lies inside the slab, the halo guarantees that -- and the fragment is zeroed in registers (v_cndmask on a
+// lane mask) instead of the ADDRESS being switched to a shared row of zeros.  The slab reads become conflict-free whatever
+// the tile's share of edge points (SQ_LDS_BANK_CONFLICT 0.29 -> 0.04 of the LDS cycles), a row block's address is one
+// base register plus an immediate, and seven address registers go away.  (The first form of this, a 256-byte zero block
+// read at the real address modulo 256, removed the conflicts too and cost 16-18 spilled registers, each reload a
+// vmcnt(0) behind 17 k-steps of weight loads in flight: +4.7 % cycles, profiles/r05_c16_zb_*.)
+template <int DBG, int RES, bool OUTF, int RB, bool WL, bool DM>
 __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const void* __restrict__ res, void* __restrict__ y,
@@ -150,22 +154,24 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   constexpr int W2_RB = RB, W2_HM = 32 * RB;
   constexpr int W2_SLABCH = ((W2_HM + 2 * 20) * 4 + 63) / 64, NPJ = (W2_SLABCH + 3) / 4;
   constexpr int W2_SLAB = W2_SLABCH * 512, W2_SLABS = W2_SLAB + 32;
-  constexpr int W2_OFF_Z = (2 * W2_SLABS + 127) / 128 * 128;            // ZB: 128 halves of zeros, 256-byte aligned
-  constexpr int W2_OFF_SC = ZB ? W2_OFF_Z + 128 : 2 * W2_SLABS, W2_OFF_OUT = W2_OFF_SC + 1024;
+  constexpr int W2_OFF_SC = 2 * W2_SLABS, W2_OFF_OUT = W2_OFF_SC + 1024;
   constexpr int TINB = RES == 0 ? 0 : (RESF ? 32 * 272 : 32 * 144), TOUTB = OUTF ? 32 * 272 : 32 * 144;   // direct epilogue tiles
   constexpr int W2_OUTB = TRICKLE ? 4 * RB * 4096 : 4 * (TINB + TOUTB);
   // WL: a ring of WD k-steps of this wave's two fragments (2 KB per k-step) in LDS; W2_D = how far ahead the fetch runs
   constexpr int WD = 6;
   constexpr int W2_OFF_W = (W2_OFF_OUT + W2_OUTB / 2 + 63) / 64 * 64;
   constexpr int W2_SMEM = WL ? W2_OFF_W + 4 * WD * 1024 : W2_OFF_OUT + W2_OUTB / 2;
-  constexpr int W2_D = WL ? WD - 1 : (RB <= 4 ? 5 : 17), W2_RING = WL ? 2 : W2_D + 1;
+  // DM: weight fragments 8 k-steps ahead through a ring of 9 register sets instead of 17 / 18 (72 registers back; the depth
+  // measured the same in round 2) -- with the 17-deep ring the DM form spills, and a reload outside any loop is still a
+  // wait behind every weight load in flight
+  constexpr int W2_D = WL ? WD - 1 : (RB <= 4 ? 5 : (DM ? 8 : 17)), W2_RING = WL ? 2 : W2_D + 1;
   static_assert(W2_OFF_OUT % 64 == 0 && 18 % W2_RING == 0 && 18 % WD == 0 && W2_KS % WD == 0, "layout");
   static_assert(W2_SMEM * 2 <= 160 * 1024, "LDS");
   // direct epilogue tiles [32 rows][64 couts]: row stride / 16-byte pieces per row / pieces per lane, per element type
   constexpr int RSB = RESF ? 272 : 144, RPR = RESF ? 16 : 8, RNP = RESF ? 8 : 4;
   constexpr int OSB = OUTF ? 272 : 144, OPR = OUTF ? 16 : 8, ONP = OUTF ? 8 : 4;
   constexpr int NRR = RESF ? 1 : W2_RR;               // 8 uint4 of ring either way
-  __shared__ __attribute__((aligned(256))) _Float16 smem[W2_SMEM];
+  __shared__ __attribute__((aligned(128))) _Float16 smem[W2_SMEM];
   const int P = N * N;
   const int M = (*d_count) * P;                          // < 2^31: 8192 x 361 rows
   const int ntiles = (M + W2_HM - 1) / W2_HM;
@@ -178,7 +184,6 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   const int nslabch = (slab * 4 + 63) / 64;
   char* sm = reinterpret_cast<char*>(smem);
   if (tid < 8) reinterpret_cast<uint4*>(smem + (tid >> 2) * W2_SLABS + W2_SLAB)[tid & 3] = make_uint4(0, 0, 0, 0);
-  if (ZB && tid < 16) reinterpret_cast<uint4*>(smem + W2_OFF_Z)[tid] = make_uint4(0, 0, 0, 0);
   {
     float* tab = reinterpret_cast<float*>(smem + W2_OFF_SC);
     tab[tid] = scale[tid];
@@ -224,19 +229,33 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   f32x16 acc[W2_RB][2];
   h8 A[W2_RB], Bf[W2_RING][2];
   int aaddr[W2_RB];
+  int abase = 0;                                          // DM: one address for the seven row blocks (+ rbk * 2048 as an immediate)
   auto tap_addr = [&](int sbuf, int tapi) __attribute__((always_inline)) {
     const int off = (tapi % 3 - 1) + N * (tapi / 3 - 1);
     const int base = sbuf * (W2_SLABS * 2);
-    int R0 = l31 + halo + off;
-    if (ZB) asm volatile("" : "+v"(R0));      // (else hipcc hoists the 18 zero-block offsets of a tile out of the chunk loop and spills)
+    const int R0 = l31 + halo + off;
     const int a0 = base + (R0 << 6) + ((((R0 >> 2) ^ hi) & 3) << 4);      // row block rbk: + rbk * 2048, same swizzle
-    const int z0 = ZB ? W2_OFF_Z * 2 + (a0 & 255) : base + W2_SLAB * 2;      // (row blocks are 2048 bytes apart: same banks)
+    if (DM) {
+      abase = a0;
+    } else {
 #pragma unroll
-    for (int rbk = 0; rbk < W2_RB; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : z0;
+      for (int rbk = 0; rbk < W2_RB; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : base + W2_SLAB * 2;
+    }
   };
   // (one register set: a row block's fragment of the next k-step is fetched right after the block's two MFMAs)
   auto read_a = [&](int ks, int rbk) __attribute__((always_inline)) {
-    A[rbk] = *reinterpret_cast<const h8*>(sm + (aaddr[rbk] ^ (ks << 5)));
+    if (DM) A[rbk] = *reinterpret_cast<const h8*>(sm + (abase ^ (ks << 5)) + rbk * 2048);
+    else A[rbk] = *reinterpret_cast<const h8*>(sm + (aaddr[rbk] ^ (ks << 5)));
+  };
+  // DM: the fragment of row block rbk as it arrived, zeroed where tap `tapi`'s neighbour is off the board (or past the batch)
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  auto mask_a = [&](int tapi, int rbk) __attribute__((always_inline)) {
+    unsigned t = vm[rbk];
+    asm volatile("" : "+v"(t));          // (recomputed per k-step: kept for the tap's second k-step the seven masks cost seven registers)
+    const unsigned m = (unsigned)(((int)(t << (31 - tapi))) >> 31);      // all ones if bit tapi is set
+    u4v raw = __builtin_bit_cast(u4v, A[rbk]);
+    raw[0] &= m; raw[1] &= m; raw[2] &= m; raw[3] &= m;
+    A[rbk] = __builtin_bit_cast(h8, raw);
   };
   const char* wfw = reinterpret_cast<const char*>(wf) + wave * 2048;
   auto load_b = [&](int slot, const char* wbase, int kk) __attribute__((always_inline)) {   // this wave's two fragments of k-step kk
@@ -374,6 +393,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
 #pragma unroll
       for (int mi = 0; mi < 2 * W2_RB; ++mi) {
         const int rbk = mi >> 1, cb = mi & 1;
+        if (DM && cb == 0) mask_a(i >> 1, rbk);
         if (DBG & 16) {
           acc[rbk][cb][mi] += (float)Bf[slot][cb][0] * (float)A[rbk][1];
         } else if (first && i == 0) {
@@ -414,8 +434,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
       if (i == 16) {
         // the slab pieces issued in k-steps 0 and 1 are older than the 2 W2_D weight fragments that may be in flight
         if (WL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WD - 1)) : "memory");
-        else if (W2_D == 17) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W2_D) : "memory");
         __syncthreads();
       }
     });
@@ -573,7 +592,7 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   if (!ncu) AGZ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
   const int rk = !res ? 0 : (res_f32 ? 2 : 1);
   const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
-  static const bool zb = getenv("AGZ_C16_ZB") && atoi(getenv("AGZ_C16_ZB")) != 0;
+  static const bool zb = getenv("AGZ_C16_DM") && atoi(getenv("AGZ_C16_DM")) != 0;
 #define AGZ_C16_W2(D, R, OF, RB, G)                                                                                                      \
   do {                                                                                                                                   \
     if (zb && (D) == 0)                                                                                                                  \
