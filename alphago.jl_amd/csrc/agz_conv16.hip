@@ -580,7 +580,7 @@ void launch_f32_to_f16(const float* x, uint16_t* y, const int* d_count, int bcap
 // as LDS-DMA into unused LDS) ran at 1.08-1.11 ms where the product takes 1.39.  Every fp16 parity test is green with it
 // -- and it takes 1.385 ms: the variants' MFMAs multiplied by a B operand that never changed, and the matrix pipe's
 // power follows its operands' toggling; with real weights in the registers the board is back on its 1305 W limit
-// whichever way they arrive.  Kept as a compile-time option, not the product.
+// whichever way they arrive (HISTORY.md 4h).  Kept as a compile-time option, not the product.
 #ifndef AGZ_C16_WL
 #define AGZ_C16_WL false
 #endif

@@ -76,7 +76,7 @@ class Net {
   bool use_wino4() const { return winograd_ && !wino_f33_only_ && precision_ == 0 && tower_ > 0 && wino4_applies(N_); }
   // the f32 Winograd tower as ONE persistent launch (k_wino_tower) instead of one launch per layer, where it applies
   // (whole-board tile blocks, 256 CUs with 32 resident workgroups per XCD); same arithmetic, same bits.  Off by
-  // default: it needs 3.7 % fewer cycles and the clock comes down by as much -- same wall time.
+  // default: it needs 3.7 % fewer cycles and the clock comes down by as much (HISTORY.md 4f) -- same wall time.
   void set_tower_persistent(bool on) { tower_persistent_ = on; }
   // Throws if a persistent tower launch that has completed raised its scheduler's error word (its outputs were
   // garbage).  Called by every forward and by the engine's synchronising calls; the caller has synchronised the stream,

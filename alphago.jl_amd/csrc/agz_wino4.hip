@@ -2,7 +2,7 @@
 // larger (BASELINE configs[3]: 19x19, tower 20).
 //
 // Why a second Winograd kernel: on the exact-f32 matrix pipe the layer is bound by MFMA work (and by the power that work
-// costs: DESIGN.md 4f), so the lever is fewer multiplies.  F(3x3,3x3) (agz_wino.hip) tiles a 19x19 board as 7x7 tiles of
+// costs: HISTORY.md 4f), so the lever is fewer multiplies.  F(3x3,3x3) (agz_wino.hip) tiles a 19x19 board as 7x7 tiles of
 // 3 over a 21-wide cover: 49 x 25 = 1225 multiplies per (cin, cout) and board, 3.39 per output point.  F(4x4,3x3) tiles
 // it as 5x5 tiles of 4 over a 20-wide cover: 25 x 36 = 900, 2.49 per point -- 27 % less MFMA work, 25 % less V traffic --
 // and f32 has four orders of magnitude of head-room on this network (|d pi| ~ 1e-8 against the 1e-4 bar).
@@ -25,7 +25,7 @@
 // + the 256 of the 16 running outputs -- nothing of either ever in scratch -- and ONE K-loop body and ONE fold (the row's
 // weights are run-time scalars) in 24 KB of code.  Every byte and every MFMA of the one-pass form is kept: a pass moves
 // only its own planes of V and U.  (History -- four passes with paired rows, 65 KB of code, tuples in scratch -- and what
-// each step measured: DESIGN.md 4g.)
+// each step measured: HISTORY.md 4g.)
 //
 // Stage = 24 UNITS; a unit = one plane x 4 input channels = 64 rows x 16 B of V and of U (1 KB each), two MFMAs per wave;
 // a stage = 6 planes x 4 channel groups = 48 KB, 16 stages per pass, 96 per layer, triple-buffered in LDS and filled by

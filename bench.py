@@ -65,7 +65,7 @@ def pmc_traffic(rows_per_launch, N, precision="f32", f43=False):
 class PowerSampler:
     """Socket power and shader clock of one GPU, sampled from the amdgpu hwmon files while a timed region runs.
 
-    The f32 MFMA layer is power-limited: its `frac` of the nominal peak only means something next to the
+    The f32 MFMA layer is power-limited (HISTORY.md 4f): its `frac` of the nominal peak only means something next to the
     clock and the watts the board actually ran at, so the line carries them.  Sources, first that works:
     hwmon power1_average / power1_input (microwatts) and freq1_input (Hz, sclk) under the device's sysfs node; the
     amdsmi Python module; nothing (the object then says so).  ~20 samples per second on a daemon thread: no GPU work."""
@@ -344,7 +344,7 @@ def main():
     ap.add_argument("--tower-streams", type=int, default=2, choices=[1, 2, 3, 4],
                     help="agz_net_set_tower_streams: the F(4x4,3x3) tower as 2 (default) or 1 layer chains")
     ap.add_argument("--tower-persistent", action="store_true",
-                    help="run the f32 Winograd tower as one persistent launch (agz_net_set_tower_persistent; same bits, DESIGN.md 4f)")
+                    help="run the f32 Winograd tower as one persistent launch (agz_net_set_tower_persistent; same bits, HISTORY.md 4f)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the 0.4 s sustained-MFMA-rate measurement behind the timed region")
     ap.add_argument("--no-alt-precision", action="store_true",
                     help="skip the extra (untimed for `value`) leg that repeats the K steps with --precision f32s")
@@ -664,7 +664,7 @@ def main():
         }
         if not f16 and not f32s and exe_tf is not None and not args.no_sustained:
             # context, not the contract's `peak`: what THIS board sustains on f32 MFMAs alone (power-limited clock), measured
-            # now, after the timed region (0.4 s of back-to-back register-only MFMA launches)
+            # now, after the timed region (0.4 s of back-to-back register-only MFMA launches; HISTORY.md 4f)
             try:
                 sus = eng.mfma_sustained_tflops(400)
                 roofline["sustained_mfma"] = {

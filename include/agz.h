@@ -147,7 +147,7 @@ agz_status agz_net_set_winograd(agz_engine* e, int32_t on);
  * wherever it applies -- board sizes whose tile blocks hold whole boards (N <= 12), a 256-CU device).  The same device
  * function does the work either way: outputs are bit-identical (tests/test_gpu_tower.py).  The persistent form needs
  * 3.7 % fewer cycles (no partly filled last workgroup round per layer) and, on a power-limited MI355X, runs at a
- * clock 4 % lower: the same wall time. */
+ * clock 4 % lower: the same wall time (HISTORY.md 4f). */
 agz_status agz_net_set_tower_persistent(agz_engine* e, int32_t on);
 /* the Winograd tower of a large batch as n = 1..4 independent layer chains (default 2): ranges of the batch's tile blocks, cut
  * at board boundaries, run their layers on n HIP streams and the hardware interleaves their workgroups (-5 % per forward

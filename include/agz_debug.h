@@ -41,7 +41,7 @@ agz_status agz_debug_live_record(agz_engine* e, int32_t g, int32_t k, uint64_t* 
 
 /* Measurement context for bench.py's roofline object: the f32 MFMA rate (TFLOP/s) this board SUSTAINS on nothing but
  * independent v_mfma_f32_32x32x2_f32 from registers -- back-to-back ~10 ms launches for `millis` (50..5000), median of the
- * second half.  On an MI355X at its power limit: ~124, i.e. 0.79 of the nominal 157.3.  Synchronises. */
+ * second half.  On an MI355X at its power limit: ~124, i.e. 0.79 of the nominal 157.3 (HISTORY.md 4f).  Synchronises. */
 agz_status agz_debug_mfma_sustained(agz_engine* e, int32_t millis, float* tflops_out);
 /* The inference weight images are built on the device from the device master copy of the parameters (DESIGN.md "weights").
  * This hook rebuilds image family `which` on the HOST from the host copies (the round-1..4 pack code, kept as the

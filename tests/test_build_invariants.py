@@ -2,7 +2,7 @@
 
 The Winograd GEMMs give one wave per SIMD the CU's whole register file and place their s_waitcnt vmcnt by hand around
 LDS-DMA streams.  A register spilled to scratch is reloaded behind an `s_waitcnt vmcnt(0)` -- a wait for every DMA piece
-in flight -- and a single such reload per K-loop pass costs percents (one extra comparison in the F(4x4,3x3)
+in flight -- and a single such reload per K-loop pass costs percents (HISTORY.md 4g: one extra comparison in the F(4x4,3x3)
 kernel's point table compiled to 416 bytes of scratch and +8 % per step).  hipcc decides this per build, so the build is
 checked: no scratch in the product instantiations of the two GEMM kernels."""
 import os

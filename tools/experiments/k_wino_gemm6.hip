@@ -5,7 +5,7 @@
 // the copy of y, the next layer's input transform: 0.40-0.45 ms of a 2.35 ms layer -- is executed by that lone wave at
 // VALU / LDS latency with the matrix pipe idle, because nothing else fits on the CU (19 % of the
 // launch).  Two resident workgroups per CU would run one's epilogue under the other's K loop, but need <= 256 registers
-// per wave.  Round 3 measured the obvious way there and why it fails ("k_wino_gemm5"): halving the tile to
+// per wave.  Round 3 measured the obvious way there and why it fails (HISTORY.md 4d, "k_wino_gemm5"): halving the tile to
 // 64 x 32 on v_mfma_f32_16x16x4_f32 (200 accumulators) makes a workgroup's own K loop too weak to use the pipe alone
 // (32-cycle MFMAs do not cover an LDS-DMA issue, 1.5x the DMA bytes per flop, double buffering): 2.62 ms per layer.
 //
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_wino_gemm6(
   //   2   the owners: next layer's input transform V = B^T d B from img -> HBM stage images (MODE & 2)
   // From here on this workgroup's waves are VALU / LDS / store work beside the OTHER workgroup's K loop on the same SIMDs.
   // The SIMD arbitrates issue by priority, then age; left at priority 0 the epilogue gets the slots the MFMA stream
-  // leaves over and takes twice as long (118 us against 59 us alone, per workgroup: wall-clock trace), while
+  // leaves over and takes twice as long (118 us against 59 us alone, per workgroup: wall-clock trace, HISTORY.md 4e), while
   // the K loop -- one 64-cycle MFMA per ~16 issue slots -- loses next to nothing by waiting a slot.
   if (X != 33) __builtin_amdgcn_s_setprio(3);
   float* img = lds;

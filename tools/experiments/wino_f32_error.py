@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which Winograd tiles hold the 1e-4 bar in f32?  (the 9x9 layer is on the board's power limit, so only
+"""Which Winograd tiles hold the 1e-4 bar in f32?  (HISTORY.md 10: the 9x9 layer is on the board's power limit, so only
 fewer multiplies move it: F(5x5,3x3) over a 10-wide cover needs 196 per channel pair and board against F(3x3,3x3)'s 225,
 an exact cover 9 = 5 + 4 with four tile shapes 169.)  CPU emulation in torch: the transforms B^T d B and A^T M A, the
 plane products summed over the input channels and the BatchNorm / residual / ReLU all in float32, U = G k G^T formed in

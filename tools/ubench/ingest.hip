@@ -1,5 +1,5 @@
 // ingest.hip -- how many bytes per clock a gfx950 CU can pull out of L2: LDS-DMA (global_load_lds_dwordx4) against plain
-// global_load_dwordx4 into registers, by waves per CU and working-set size.  Measurement tool for DESIGN.md (round 3): the
+// global_load_dwordx4 into registers, by waves per CU and working-set size.  Measurement tool for HISTORY.md 4d (round 3): the
 // Winograd GEMM's K loop is fed by LDS-DMA, and its tile shape (flop per DMA byte) has to respect this ceiling.
 //   hipcc --offload-arch=gfx950 -O3 -o ingest ingest.hip && ./ingest
 #include <hip/hip_runtime.h>

@@ -1,6 +1,6 @@
 // mfma_valu.hip -- does a wave's f32 VALU work run beside ANOTHER wave's MFMAs on the same SIMD?  gfx950's f32-input MFMA
 // runs at the f32 vector rate (64 FLOP/clk/SIMD); if it executes on the vector ALU's own FMA lanes, a VALU-bound epilogue
-// cannot hide under a co-resident workgroup's f32 K loop (k_wino_gemm6), whereas under an f16/bf16 MFMA it can.
+// cannot hide under a co-resident workgroup's f32 K loop (k_wino_gemm6, HISTORY.md 4d), whereas under an f16/bf16 MFMA it can.
 // A workgroup = 8 waves, two per SIMD: waves 0-3 issue MFMAs, waves 4-7 independent v_fma_f32 chains.
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_valu mfma_valu.hip && ./mfma_valu
 #include <hip/hip_runtime.h>
