@@ -62,6 +62,51 @@ def pmc_traffic(rows_per_launch, N, precision="f32", f43=False):
     return None, None
 
 
+def live_pmc_traffic(args, seconds_cap=240.0):
+    """HBM bytes per tower layer measured NOW, on this box: two child runs of this very command under `rocprofv3 --pmc`
+    (FETCH_SIZE, then WRITE_SIZE: separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes), a few steps each
+    with one tower chain so that a dispatch is a layer, summarised by tools/pmc_traffic.py (FETCH doubled for 16 B/lane
+    streaming reads).  Returns (bytes_per_row, source) or (None, why).  Hardware counters cannot be read from inside a
+    process that is not being profiled, hence the children; the parent's engine is idle meanwhile."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "no rocprofv3 on this host"
+    spec = importlib.util.spec_from_file_location("agz_pmc_traffic", os.path.join(ROOT, "tools", "pmc_traffic.py"))
+    pt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pt)
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(prefix="agz_pmc_", dir="/tmp") as tmp:
+        dirs = []
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--board", str(args.board), "--tower", str(args.tower),
+                   "--readouts", str(args.readouts), "--games", str(args.games), "--stagger", str(args.stagger),
+                   "--precision", args.precision, "--winograd", str(args.winograd), "--tower-streams", "1", "--no-cpu-baseline",
+                   "--no-alt-precision", "--no-config-legs", "--generation", "0", "--no-sustained", "--no-live-traffic"]
+            left = seconds_cap - (time.time() - t0)
+            if left < 20:
+                return None, f"counter passes over their {seconds_cap:.0f} s budget"
+            try:
+                r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.PIPE, text=True, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
+            dirs.append(d)
+        try:
+            d = pt.summarise(8 * args.games, args.board, dirs)
+        except Exception as ex:
+            return None, f"{type(ex).__name__}: {ex}"
+    return d["bytes_per_row"], (f"live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command on this box, "
+                                f"{d['tower_layer_dispatches']} tower-layer dispatches, {time.time() - t0:.0f} s")
+
+
 class PowerSampler:
     """Socket power and shader clock of one GPU, sampled from the amdgpu hwmon files while a timed region runs.
 
@@ -261,6 +306,7 @@ def shard_leg(ag, torch, name, N, tower, R, games, precision, steps, warmup, sta
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
         alg = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
         pos = s1["positions"] - s0["positions"]
+        traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), N, precision, not f16)
         return {
             "config": name, "precision": precision,
             "workload": f"GoEnv({N}), tower_height={tower}, {R} readouts, {games} concurrent games on this GPU "
@@ -271,7 +317,9 @@ def shard_leg(ag, torch, name, N, tower, R, games, precision, steps, warmup, sta
             "roofline": {"bound": "mfma", "kernel": "k_conv3x3_f16_w2 (implicit GEMM, v_mfma_f32_32x32x16_f16)" if f16 else
                                   "Winograd F(4x4,3x3) tower layer (v_mfma_f32_32x32x2_f32; every kernel of a layer timed together)",
                          "achieved": alg * ratio if alg else None, "peak": peak, "unit": "TFLOP/s",
-                         "frac": alg * ratio / peak if alg else None, "achieved_algorithmic": alg},
+                         "frac": alg * ratio / peak if alg else None, "achieved_algorithmic": alg,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": (1280.0 if f16 else 2560.0) * conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256)},
             "end_to_end_algorithmic_tflops": pos / dt * R * f_eval(N, tower) / 1e12,
             "power": power,
             "pool": {"node_capacity": s1["node_capacity"], "peak_nodes_per_game": s1["peak_nodes_per_game"],
@@ -357,6 +405,9 @@ def main():
     ap.add_argument("--generation-seconds", type=float, default=900.0,
                     help="hard cap on the generation leg (half for the warm-up generation, half for the measured one); a leg the "
                          "cap cut short reports what it saw and says so")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from the committed profiles/ file instead of two live rocprofv3 --pmc passes of this "
+                         "command (the default at N = 1 on the headline workload when rocprofv3 is installed)")
     ap.add_argument("--no-config-legs", action="store_true",
                     help="skip the two bounded legs that run one GPU's shard of BASELINE configs[3] (19x19, tower 20, 800 "
                          "readouts, 256 games, f32) and configs[4] (fp16 tower, 1600 readouts, 512 games) after the headline")
@@ -622,7 +673,20 @@ def main():
         T4 = (N + 3) // 4
         wino_ratio = 1.0 if f16 else (36.0 * T4 * T4 / (9.0 * N * N) if f43 else 25.0 * T * T / (9.0 * N * N))
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), N, args.precision, f43)
+        rows_per_launch = conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256)
+        traffic_committed = None
+        traffic, traffic_src = pmc_traffic(rows_per_launch, N, args.precision, f43)
+        if world == 1 and headline and args.stagger > 0 and not args.no_live_traffic:
+            # driver-witnessed: counters collected on THIS box, now; the committed file is the fallback
+            try:
+                bpr, src = live_pmc_traffic(args)
+            except Exception as ex:
+                bpr, src = None, f"{type(ex).__name__}: {ex}"
+            if bpr is not None:
+                traffic_committed = traffic
+                traffic, traffic_src = bpr * rows_per_launch, src
+            else:
+                traffic_src = f"{traffic_src}; live passes unavailable ({src})"
         # The roofline object.  `achieved`/`frac` are what the MFMA pipe EXECUTES: Winograd F(3x3,3x3) needs 25
         # multiplies per 3x3 output tile and (cin, cout) pair instead of 81, all of them still f32, so the
         # honest fraction of the f32 MFMA peak is executed flops / time / peak (<= 1).  The rate in terms of the
@@ -657,6 +721,7 @@ def main():
                     "stream around every tower-conv launch of the timed region); achieved_algorithmic = 2*rows*9*256*256 "
                     "per launch / the same time",
             "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_from_committed_profile": traffic_committed,      # (set when `traffic` was measured live: the file's figure beside it)
             "algorithmic_bytes_per_launch": (1280.0 if f16 else 2560.0) * conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256),
             "launches_timed": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
             "executed_flop_per_launch_avg": conv_flop * wino_ratio / max(conv_n, 1),

@@ -23,39 +23,47 @@ import glob
 import json
 import sys
 
-B, N = int(sys.argv[1]), int(sys.argv[2])
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in sys.argv[3:]:
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-rows = B * N * N
-per_kernel, counts = {}, {}
-total = 0.0
-layers = 0
-for k, cs in agg.items():
-    if "wino" not in k and "conv3x3_f16" not in k:
-        continue
-    # bytes summed over every dispatch of the run; a tower layer = one GEMM dispatch (k_wino_in runs once per forward)
-    per_kernel[k] = {c: 1024.0 * sum(v) for c, v in cs.items()}
-    counts[k] = max(len(v) for v in cs.values())
-    stem = k.rstrip().endswith(", 8>")          # the stem's 8-stage GEMM and its feature-plane transform: listed, not counted
-    if ("gemm" in k or "conv3x3_f16" in k) and not stem:
-        layers += counts[k]
-    # MI355X_MICROARCH.md, HBM: "FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane,
-    # global_load and buffer_load ... lds alike) -- double it before comparing with a byte count".  Every read of these
-    # kernels is of that kind (k_wino_in: 8 B/lane on 64-B runs was calibrated x2 in round 1 on its compulsory input).
-    if "FETCH_SIZE" in per_kernel[k]:
-        per_kernel[k]["FETCH_SIZE_raw"] = per_kernel[k]["FETCH_SIZE"]
-        per_kernel[k]["FETCH_SIZE"] *= 2.0
-    if not stem:
-        total += sum(v for c, v in per_kernel[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE"))
-layers = max(layers, 1)
-print(json.dumps({
-    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the bench.py command, <= {B} positions per launch, {N}x{N}, gfx950; KiB counters; "
-              "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads (raw kept); bytes of ALL "
-              "tower-layer Winograd kernels of the run / number of tower-layer GEMM dispatches (the stem's 8-stage GEMM is listed, not counted)",
-    "rows_per_launch": rows, "tower_layer_dispatches": layers, "bytes_per_launch": total / layers, "bytes_per_row": total / layers / rows,
-    "algorithmic_bytes_per_row": 2.5 * 256 * 4, "board": N,
-    "per_kernel_total_bytes": per_kernel, "per_kernel_dispatches": counts,
-}, indent=1))
+
+def summarise(B, N, dirs):
+    """the pmc_traffic object from the counter_collection.csv files under `dirs` (one FETCH_SIZE pass, one WRITE_SIZE pass)"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows = B * N * N
+    per_kernel, counts = {}, {}
+    total = 0.0
+    layers = 0
+    for k, cs in agg.items():
+        if "wino" not in k and "conv3x3_f16" not in k:
+            continue
+        # bytes summed over every dispatch of the run; a tower layer = one GEMM dispatch (k_wino_in runs once per forward)
+        per_kernel[k] = {c: 1024.0 * sum(v) for c, v in cs.items()}
+        counts[k] = max(len(v) for v in cs.values())
+        stem = k.rstrip().endswith(", 8>")          # the stem's 8-stage GEMM and its feature-plane transform: listed, not counted
+        if ("gemm" in k or "conv3x3_f16" in k) and not stem:
+            layers += counts[k]
+        # MI355X_MICROARCH.md, HBM: "FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane,
+        # global_load and buffer_load ... lds alike) -- double it before comparing with a byte count".  Every read of these
+        # kernels is of that kind (k_wino_in: 8 B/lane on 64-B runs was calibrated x2 in round 1 on its compulsory input).
+        if "FETCH_SIZE" in per_kernel[k]:
+            per_kernel[k]["FETCH_SIZE_raw"] = per_kernel[k]["FETCH_SIZE"]
+            per_kernel[k]["FETCH_SIZE"] *= 2.0
+        if not stem:
+            total += sum(v for c, v in per_kernel[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE"))
+    have = {c for cs in per_kernel.values() for c in cs}
+    if not layers or not {"FETCH_SIZE", "WRITE_SIZE"} <= have:
+        raise RuntimeError(f"no tower-layer dispatches with both counters under {dirs} (have {sorted(have)}, {layers} layers)")
+    return {
+        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the bench.py command, <= {B} positions per launch, {N}x{N}, gfx950; KiB counters; "
+                  "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads (raw kept); bytes of ALL "
+                  "tower-layer Winograd kernels of the run / number of tower-layer GEMM dispatches (the stem's 8-stage GEMM is listed, not counted)",
+        "rows_per_launch": rows, "tower_layer_dispatches": layers, "bytes_per_launch": total / layers, "bytes_per_row": total / layers / rows,
+        "algorithmic_bytes_per_row": 2.5 * 256 * 4, "board": N,
+        "per_kernel_total_bytes": per_kernel, "per_kernel_dispatches": counts,
+    }
+
+
+if __name__ == "__main__":
+    print(json.dumps(summarise(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3:]), indent=1))
