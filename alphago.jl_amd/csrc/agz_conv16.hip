@@ -161,10 +161,10 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   constexpr int WD = 6;
   constexpr int W2_OFF_W = (W2_OFF_OUT + W2_OUTB / 2 + 63) / 64 * 64;
   constexpr int W2_SMEM = WL ? W2_OFF_W + 4 * WD * 1024 : W2_OFF_OUT + W2_OUTB / 2;
-  // DM: weight fragments 8 k-steps ahead through a ring of 9 register sets instead of 17 / 18 (72 registers back; the depth
-  // measured the same in round 2) -- with the 17-deep ring the DM form spills, and a reload outside any loop is still a
-  // wait behind every weight load in flight
-  constexpr int W2_D = WL ? WD - 1 : (RB <= 4 ? 5 : (DM ? 8 : 17)), W2_RING = WL ? 2 : W2_D + 1;
+  // DM, and the two direct-epilogue layers of a tower (f32 residual in: first block; f32 out: last): weight fragments 8
+  // k-steps ahead through a ring of 9 register sets instead of 17 / 18 (72 registers back) -- with the 17-deep ring those forms
+  // spill 29-44 registers, and a reload, even outside any loop, is a wait behind every weight load in flight
+  constexpr int W2_D = WL ? WD - 1 : (RB <= 4 ? 5 : ((DM || RESF || OUTF) ? 8 : 17)), W2_RING = WL ? 2 : W2_D + 1;
   static_assert(W2_OFF_OUT % 64 == 0 && 18 % W2_RING == 0 && 18 % WD == 0 && W2_KS % WD == 0, "layout");
   static_assert(W2_SMEM * 2 <= 160 * 1024, "LDS");
   // direct epilogue tiles [32 rows][64 couts]: row stride / 16-byte pieces per row / pieces per lane, per element type
@@ -559,6 +559,230 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 5: the same convolution with the four waves of a workgroup arranged 2 x 2 over a 256-row x 256-cout tile -- a
+// wave owns 128 rows x 128 couts (4 x 4 accumulator tiles = all 256 AGPRs) instead of 224 x 64.  Per k-step a wave then
+// reads 4 slab fragments (4 KB) and 4 weight fragments (4 KB) for 16 MFMAs, where the 7 x 2 form reads 7 + 2 for 14: the
+// LDS operand reads per row halve (16 KB per k-step and CU for 256 rows against 28 KB for 224), the two waves of a cout half
+// ask the TCP for the same weight lines, and a wave issues 8 memory instructions per 16 MFMAs.  Half-in / half-out layers
+// only (38 of a tower's 40; the f32-residual and f32-output layers keep k_conv3x3_f16_w2): results leave through
+// wave-private 32 x 128 tiles (the result image of a 256-row tile does not fit beside the slabs), weight fragments 8
+// k-steps ahead through a ring of 9.  Same reduction order per output (chunk, tap, k) as the 7 x 2 form: bit-identical results.
+constexpr int QM = 256;                              // rows per tile
+template <int RES>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const _Float16* __restrict__ res, _Float16* __restrict__ y,
+                                                         const int* __restrict__ d_count, int N, int relu) {
+  constexpr int SLABCH = ((QM + 2 * 20) * 4 + 63) / 64, NPJ = (SLABCH + 3) / 4;      // 1 KB pieces of a slab (halo <= 20 rows a side)
+  constexpr int SLAB = SLABCH * 512, SLABS = SLAB + 32;                              // halves; + one 64-byte row of zeros
+  constexpr int OFF_SC = 2 * SLABS, OFF_T = OFF_SC + 1024;
+  constexpr int TSB = 272, TB = 32 * TSB;                                            // epilogue tile: 32 rows x 128 halves, row stride 272 B
+  constexpr int SMEM = OFF_T + 4 * 2 * TB / 2;
+#ifndef AGZ_C16_QD
+#define AGZ_C16_QD 5
+#endif
+  constexpr int D = AGZ_C16_QD, RING = D + 1;
+  static_assert(SMEM * 2 <= 160 * 1024 && 18 % RING == 0, "layout");
+  __shared__ __attribute__((aligned(128))) _Float16 smem[SMEM];
+  const int P = N * N;
+  const int M = (*d_count) * P;
+  const int ntiles = (M + QM - 1) / QM;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int halo = N + 1, slab = QM + 2 * halo;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;                 // row half / cout half of this wave
+  const int l31 = lane & 31, hi = lane >> 5;
+  const unsigned s0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)&smem[0];
+  const int nslabch = (slab * 4 + 63) / 64;
+  char* sm = reinterpret_cast<char*>(smem);
+  if (tid < 8) reinterpret_cast<uint4*>(smem + (tid >> 2) * SLABS + SLAB)[tid & 3] = make_uint4(0, 0, 0, 0);
+  {
+    float* tab = reinterpret_cast<float*>(smem + OFF_SC);
+    tab[tid] = scale[tid];
+    tab[256 + tid] = shift[tid];
+  }
+  const float invP = 1.f / (float)P, invN = 1.f / (float)N;
+  const unsigned wlane = (unsigned)lane * 16u;
+
+  unsigned aoff[NPJ];
+  auto slab_src = [&](int m0) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) {
+      int c = wave + 4 * j;
+      c = c < nslabch ? c : nslabch - 1;
+      const int slot = c * 64 + ln, sr = slot >> 2, q = (slot & 3) ^ ((sr >> 2) & 3);
+      int g = m0 - halo + sr;
+      g = g < 0 ? 0 : (g >= M ? M - 1 : g);
+      aoff[j] = (unsigned)g * (unsigned)(kC * 2) + (unsigned)(q * 16);
+    }
+  };
+  auto dma_a = [&](int cc, int buf, int j) __attribute__((always_inline)) {
+    int c = wave + 4 * j;
+    c = c < nslabch ? c : nslabch - 1;
+    glds16hs(x + cc * HK, aoff[j], s0 + (unsigned)(buf * SLABS + c * 512) * 2u);
+  };
+  unsigned vm[4];
+  auto tile_masks = [&](int m0) __attribute__((always_inline)) {
+    const int p0 = m0 % P;
+#pragma unroll
+    for (int rbk = 0; rbk < 4; ++rbk) {
+      const int lr = wr * 128 + rbk * 32 + l31, v = p0 + lr;          // < P + 256: the float quotients below are exact
+      const int p = v - (int)(((float)v + 0.5f) * invP) * P;
+      const int bj = (int)(((float)p + 0.5f) * invN), bi = p - bj * N;
+      const unsigned cm = (bi > 0 ? 1u : 0u) | 2u | (bi < N - 1 ? 4u : 0u);
+      const unsigned mk = (bj > 0 ? cm : 0u) | (cm << 3) | (bj < N - 1 ? cm << 6 : 0u);
+      vm[rbk] = m0 + lr < M ? mk : 0u;
+    }
+  };
+  f32x16 acc[4][4];
+  h8 A[4], Bf[RING][4];
+  int aaddr[4];
+  auto tap_addr = [&](int sbuf, int tapi) __attribute__((always_inline)) {
+    const int off = (tapi % 3 - 1) + N * (tapi / 3 - 1);
+    const int base = sbuf * (SLABS * 2);
+    const int R0 = wr * 128 + l31 + halo + off;
+    const int a0 = base + (R0 << 6) + ((((R0 >> 2) ^ hi) & 3) << 4);
+#pragma unroll
+    for (int rbk = 0; rbk < 4; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : base + SLAB * 2;
+  };
+  auto read_a = [&](int ks, int rbk) __attribute__((always_inline)) {
+    A[rbk] = *reinterpret_cast<const h8*>(sm + (aaddr[rbk] ^ (ks << 5)));
+  };
+  const char* wfw = reinterpret_cast<const char*>(wf) + wc * 4096;
+  auto load_b = [&](int slot, const char* wbase, int kk) __attribute__((always_inline)) {
+    const char* p = wbase + (size_t)kk * 8192 + wlane;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) Bf[slot][cb] = *reinterpret_cast<const h8*>(p + cb * 1024);
+  };
+  char* Tin = sm + OFF_T * 2 + wave * (2 * TB);
+  char* Tout = Tin + TB;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * QM;
+    slab_src(m0);
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) dma_a(0, 0, j);
+    {
+      unsigned o = 0;
+      asm volatile("" : "+s"(o));                // (opaque per tile: else the eight fragment addresses become hoisted 64-bit lane pointers)
+      const char* wb0 = wfw + o;
+#pragma unroll
+      for (int k = 0; k < D; ++k) load_b(k, wb0, k);
+    }
+    tile_masks(m0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tap_addr(0, 0);
+#pragma unroll
+    for (int rbk = 0; rbk < 4; ++rbk) read_a(0, rbk);
+
+    auto chunk = [&](int cc, auto firstc, auto lastc) __attribute__((always_inline)) {
+      constexpr bool first = decltype(firstc)::value, last = decltype(lastc)::value;
+      const int sbuf = cc & 1;
+      unsigned wboff = 0;
+      asm volatile("" : "+s"(wboff));            // (per chunk: keeps hipcc from hoisting 18 k-steps of addresses and mask tests)
+      const char* wb = wfw + wboff;
+#pragma unroll
+      for (int rbk = 0; rbk < 4; ++rbk) asm volatile("" : "+v"(vm[rbk]));
+      static_for<0, 18>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int slot = i % RING;
+        constexpr int nks = (i + 1) & 1;
+        if (nks == 0) {
+          if (i < 17) tap_addr(sbuf, (i + 1) >> 1);
+          else if (!last) tap_addr(sbuf ^ 1, 0);
+        }
+        int kn = cc * 18 + i + D;
+        kn = kn >= W2_KS ? kn - W2_KS : kn;      // (the last chunk's tail fetches the next tile's first fragments: same addresses)
+#pragma unroll
+        for (int rbk = 0; rbk < 4; ++rbk) {
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            if (first && i == 0) {
+              const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+              acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bf[slot][cb], A[rbk], z, 0, 0, 0);
+            } else {
+              acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bf[slot][cb], A[rbk], acc[rbk][cb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (i < 17 || !last) read_a(nks, rbk);
+          if (rbk == 0 && !(last && i + D >= 18)) load_b((i + D) % RING, wb, kn);
+          if (!last && i < 2 && rbk >= 1 && (i * 3 + rbk - 1) < NPJ) dma_a(cc + 1, sbuf ^ 1, i * 3 + rbk - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i == 16 && !last) {
+          // the slab pieces issued in k-steps 0 and 1 are older than the 4 D weight fragments that may be in flight
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * D) : "memory");
+          __syncthreads();
+        }
+      });
+    };
+    chunk(0, std::true_type{}, std::false_type{});
+    for (int cc = 1; cc < HCH - 1; ++cc) chunk(cc, std::false_type{}, std::false_type{});
+    chunk(HCH - 1, std::false_type{}, std::true_type{});
+
+    // ---- epilogue: value = act(scale * acc + shift (+ residual)); acc[r][cb][4q + k] is row wr*128 + r*32 + l31,
+    // cout wc*128 + cb*32 + 8q + 4hi + k.  Residual and result cross a wave-private 32 x 128 tile each.
+    const float* tab = reinterpret_cast<const float*>(smem + OFF_SC);
+    const float lo = relu ? 0.f : -3.0e38f;
+    int eln = lane;
+    asm volatile("" : "+v"(eln));              // (opaque: else hipcc computes ~40 epilogue addresses before the K loop and spills them)
+    const int el31 = eln & 31, ehi = eln >> 5;
+    static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      const int mr = m0 + wr * 128 + r * 32;
+      if (RES != 0) {
+        // (scalars, not an array: hipcc moves a by-reference captured array into LDS)
+        auto rload = [&](int i) __attribute__((always_inline)) {
+          const int pc = eln + 64 * i, row = pc >> 4, c16 = pc & 15;
+          int m = mr + row;
+          m = m < M ? m : M - 1;
+          return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(res) + ((size_t)m * kC + wc * 128) * 2 + c16 * 16);
+        };
+        auto rput = [&](int i, uint4 v) __attribute__((always_inline)) {
+          const int pc = eln + 64 * i, row = pc >> 4, c16 = pc & 15;
+          *reinterpret_cast<uint4*>(Tin + row * TSB + c16 * 16) = v;
+        };
+        const uint4 r0 = rload(0), r1 = rload(1), r2 = rload(2), r3 = rload(3), r4 = rload(4), r5 = rload(5), r6 = rload(6), r7 = rload(7);
+        rput(0, r0); rput(1, r1); rput(2, r2); rput(3, r3); rput(4, r4); rput(5, r5); rput(6, r6); rput(7, r7);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = cb * 32 + 8 * q + 4 * ehi;
+          const float4 sc = *reinterpret_cast<const float4*>(tab + wc * 128 + n);
+          const float4 sh = *reinterpret_cast<const float4*>(tab + 256 + wc * 128 + n);
+          float v0 = acc[r][cb][4 * q + 0] * sc.x + sh.x, v1 = acc[r][cb][4 * q + 1] * sc.y + sh.y;
+          float v2 = acc[r][cb][4 * q + 2] * sc.z + sh.z, v3 = acc[r][cb][4 * q + 3] * sc.w + sh.w;
+          if (RES != 0) {
+            const h4 rv = *reinterpret_cast<const h4*>(Tin + el31 * TSB + n * 2);
+            v0 += (float)rv[0]; v1 += (float)rv[1]; v2 += (float)rv[2]; v3 += (float)rv[3];
+          }
+          v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+          *reinterpret_cast<h4*>(Tout + el31 * TSB + n * 2) = h4{(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+        }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pc = eln + 64 * i, row = pc >> 4, c16 = pc & 15;
+        const int m = mr + row;
+        if (m < M)
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + ((size_t)m * kC + wc * 128) * 2 + c16 * 16) =
+              *reinterpret_cast<const uint4*>(Tout + row * TSB + c16 * 16);
+      }
+      asm volatile("" ::: "memory");
+    });
+    __syncthreads();        // every wave is done with both slabs before the next tile's first slab arrives
+  }
+}
+
 __global__ __launch_bounds__(256) void k_f32_to_f16(const float* __restrict__ x, _Float16* __restrict__ y,
                                                      const int* __restrict__ d_count, long per_position) {
   const long n = (long)(*d_count) * per_position;        // multiple of 8
@@ -591,6 +815,14 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   static int ncu = 0;
   if (!ncu) AGZ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
   const int rk = !res ? 0 : (res_f32 ? 2 : 1);
+  // AGZ_C16_Q=1: half-in / half-out layers on the 2 x 2 form (k_conv3x3_f16_q); the f32-residual / f32-output layers stay here
+  static const bool quad = getenv("AGZ_C16_Q") && atoi(getenv("AGZ_C16_Q")) != 0;
+  if (quad && !res_f32 && !out_f32) {
+    const int gq = std::min((int)((rows + QM - 1) / QM), ncu);
+    if (res) hipLaunchKernelGGL((k_conv3x3_f16_q<1>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)res, (_Float16*)y, d_count, N, relu);
+    else hipLaunchKernelGGL((k_conv3x3_f16_q<0>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)nullptr, (_Float16*)y, d_count, N, relu);
+    return;
+  }
   const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
   static const bool zb = getenv("AGZ_C16_DM") && atoi(getenv("AGZ_C16_DM")) != 0;
 #define AGZ_C16_W2(D, R, OF, RB, G)                                                                                                      \

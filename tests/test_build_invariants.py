@@ -38,3 +38,14 @@ def test_winograd_gemm_kernels_use_no_scratch(src, kernel, bound):
     sizes = {k: v for k, v in _scratch_sizes(src).items() if kernel in k}
     assert len(sizes) >= 3, sizes
     assert all(v <= bound for v in sizes.values()), {k: v for k, v in sizes.items() if v > bound}
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="no hipcc")
+def test_fp16_tower_kernel_uses_no_scratch_in_any_product_form():
+    """k_conv3x3_f16_w2 sits at 512 of 512 registers with its weight fragments 17 k-steps ahead in flight: a reload is a wait
+    behind all of them.  Round 5: the two direct-epilogue forms of a tower (f32 residual in / f32 out) spilled 29-44
+    registers with the 18-deep weight ring and take a 9-deep one; every product form (DBG = 0, RB = 7, DM = 0) now compiles
+    to at most one spilled dword (the half-in / half-out form with a residual: 8 bytes, outside its chunk loop)."""
+    sizes = {k: v for k, v in _scratch_sizes("agz_conv16.hip").items() if "k_conv3x3_f16_w2ILi0E" in k and "ELi7ELb0ELb0E" in k}
+    assert len(sizes) == 6, sizes
+    assert all(v <= 8 for v in sizes.values()), {k: v for k, v in sizes.items() if v > 8}
