@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
   constexpr int SLABCH = ((QM + 2 * 20) * 4 + 63) / 64, NPJ = (SLABCH + 3) / 4;      // 1 KB pieces of a slab (halo <= 20 rows a side)
   constexpr int SLAB = SLABCH * 512, SLABS = SLAB + 32;                              // halves; + one 64-byte row of zeros
   constexpr int OFF_SC = 2 * SLABS, OFF_T = OFF_SC + 1024;
-  constexpr int TSB = 272, TB = 32 * TSB;                                            // epilogue tile: 32 rows x 128 halves, row stride 272 B
+  constexpr int TSB = 264, TB = 32 * TSB;                                            // epilogue tile: 32 rows x 128 halves, row stride 264 B (66 dwords: a lane = row access of 8 bytes is conflict-free)
   constexpr int SMEM = OFF_T + 4 * 2 * TB / 2;
 #ifndef AGZ_C16_QD
 #define AGZ_C16_QD 5
@@ -661,24 +661,23 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
   char* Tin = sm + OFF_T * 2 + wave * (2 * TB);
   char* Tout = Tin + TB;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int m0 = tile * QM;
-    slab_src(m0);
+  int tile = blockIdx.x;
+  int m0 = tile * QM;
+  slab_src(m0);
 #pragma unroll
-    for (int j = 0; j < NPJ; ++j) dma_a(0, 0, j);
-    {
-      unsigned o = 0;
-      asm volatile("" : "+s"(o));                // (opaque per tile: else the eight fragment addresses become hoisted 64-bit lane pointers)
-      const char* wb0 = wfw + o;
+  for (int j = 0; j < NPJ; ++j) dma_a(0, 0, j);
 #pragma unroll
-      for (int k = 0; k < D; ++k) load_b(k, wb0, k);
-    }
-    tile_masks(m0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    tap_addr(0, 0);
+  for (int k = 0; k < D; ++k) load_b(k, wfw, k);
+  tile_masks(m0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  tap_addr(0, 0);
 #pragma unroll
-    for (int rbk = 0; rbk < 4; ++rbk) read_a(0, rbk);
+  for (int rbk = 0; rbk < 4; ++rbk) read_a(0, rbk);
+
+  for (;;) {
+    const int next_tile = tile + gridDim.x;
+    const bool more = next_tile < ntiles;
 
     auto chunk = [&](int cc, auto firstc, auto lastc) __attribute__((always_inline)) {
       constexpr bool first = decltype(firstc)::value, last = decltype(lastc)::value;
@@ -711,11 +710,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
             __builtin_amdgcn_sched_barrier(0);
           }
           if (i < 17 || !last) read_a(nks, rbk);
-          if (rbk == 0 && !(last && i + D >= 18)) load_b((i + D) % RING, wb, kn);
-          if (!last && i < 2 && rbk >= 1 && (i * 3 + rbk - 1) < NPJ) dma_a(cc + 1, sbuf ^ 1, i * 3 + rbk - 1);
+          if (rbk == 0) load_b((i + D) % RING, wb, kn);
+          // the next chunk's slab (the next tile's first, in the last chunk) goes out in k-steps 0 and 1
+          // (after the last tile the spare buffer just receives a slab once more: no branch in the loop)
+          if (i < 2 && rbk >= 1 && (i * 3 + rbk - 1) < NPJ) dma_a(last ? 0 : cc + 1, sbuf ^ 1, i * 3 + rbk - 1);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (i == 16 && !last) {
+        if (i == 16) {
           // the slab pieces issued in k-steps 0 and 1 are older than the 4 D weight fragments that may be in flight
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * D) : "memory");
           __syncthreads();
@@ -724,6 +725,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
     };
     chunk(0, std::true_type{}, std::false_type{});
     for (int cc = 1; cc < HCH - 1; ++cc) chunk(cc, std::false_type{}, std::false_type{});
+    if (more) slab_src(next_tile * QM);          // the last chunk sends the next tile's first slab and weight fragments ahead
     chunk(HCH - 1, std::false_type{}, std::true_type{});
 
     // ---- epilogue: value = act(scale * acc + shift (+ residual)); acc[r][cb][4q + k] is row wr*128 + r*32 + l31,
@@ -744,9 +746,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
           m = m < M ? m : M - 1;
           return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(res) + ((size_t)m * kC + wc * 128) * 2 + c16 * 16);
         };
-        auto rput = [&](int i, uint4 v) __attribute__((always_inline)) {
+        auto rput = [&](int i, uint4 v) __attribute__((always_inline)) {        // (row stride 264 B: 8-byte LDS accesses)
           const int pc = eln + 64 * i, row = pc >> 4, c16 = pc & 15;
-          *reinterpret_cast<uint4*>(Tin + row * TSB + c16 * 16) = v;
+          *reinterpret_cast<uint2*>(Tin + row * TSB + c16 * 16) = make_uint2(v.x, v.y);
+          *reinterpret_cast<uint2*>(Tin + row * TSB + c16 * 16 + 8) = make_uint2(v.z, v.w);
         };
         const uint4 r0 = rload(0), r1 = rload(1), r2 = rload(2), r3 = rload(3), r4 = rload(4), r5 = rload(5), r6 = rload(6), r7 = rload(7);
         rput(0, r0); rput(1, r1); rput(2, r2); rput(3, r3); rput(4, r4); rput(5, r5); rput(6, r6); rput(7, r7);
@@ -773,13 +776,20 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
       for (int i = 0; i < 8; ++i) {
         const int pc = eln + 64 * i, row = pc >> 4, c16 = pc & 15;
         const int m = mr + row;
+        const uint2 o0 = *reinterpret_cast<const uint2*>(Tout + row * TSB + c16 * 16);
+        const uint2 o1 = *reinterpret_cast<const uint2*>(Tout + row * TSB + c16 * 16 + 8);
         if (m < M)
-          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + ((size_t)m * kC + wc * 128) * 2 + c16 * 16) =
-              *reinterpret_cast<const uint4*>(Tout + row * TSB + c16 * 16);
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + ((size_t)m * kC + wc * 128) * 2 + c16 * 16) = make_uint4(o0.x, o0.y, o1.x, o1.y);
       }
       asm volatile("" ::: "memory");
     });
-    __syncthreads();        // every wave is done with both slabs before the next tile's first slab arrives
+    if (!more) break;
+    tile = next_tile;
+    m0 = tile * QM;
+    tile_masks(m0);
+    tap_addr(0, 0);
+#pragma unroll
+    for (int rbk = 0; rbk < 4; ++rbk) read_a(0, rbk);
   }
 }
 
