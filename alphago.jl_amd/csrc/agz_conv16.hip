@@ -121,6 +121,21 @@ void launch_conv16_pack(const float* d_w, long wstride, int layers, uint16_t* d_
 __device__ unsigned g_c16_pace = 0;
 #endif
 
+// Cache policy of the result stores / residual loads of the trickled epilogue, set once from AGZ_C16_POLICY (round 5
+// experiment, HISTORY.md 12): bits 0-1 = stores plain / sc1 (write-through: the line does not stay in this XCD's L2, where
+// it would push the 1.2 MB of weights every tile re-reads out) / nt / sc0 sc1.  (A second switch on the residual loads
+// made the residual-carrying form spill 25 registers: this kernel has no register to give.)
+__device__ unsigned g_c16_policy = 0;
+typedef unsigned c16_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void c16_store(c16_u4* gp, c16_u4 v, unsigned pol) {
+  switch (pol & 3u) {
+    case 1: asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gp), "v"(v) : "memory"); break;
+    case 2: asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(gp), "v"(v) : "memory"); break;
+    case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(gp), "v"(v) : "memory"); break;
+    default: *gp = v;
+  }
+}
+
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < E) {
@@ -302,6 +317,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   const int lx = l31 * 512 + 8 * hi + (((wave * 8) ^ l31) << 4);                              // lane's 8-byte group: lx ^ (piece << 4), piece 0..7 of the slice
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   u4 treg = {0, 0, 0, 0};
+  const unsigned pol = __builtin_amdgcn_readfirstlane(g_c16_policy);
   char* yprev = nullptr;                                  // tile whose image is leaving: base of its rows in y
 
   int tile = blockIdx.x;
@@ -358,8 +374,8 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
       const int pc = lane + 64 * i, row = pc / RPR, c16 = pc % RPR;
       int m = m0 + r * 32 + row;
       m = m < M ? m : M - 1;                              // rows past the batch: any value, never used
-      rr(std::integral_constant<int, (r % NRR) * RNP + i>{}) =
-          *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(res) + ((size_t)m * kC + wave * 64) * (RESF ? 4 : 2) + c16 * 16);
+      const uint4* rp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(res) + ((size_t)m * kC + wave * 64) * (RESF ? 4 : 2) + c16 * 16);
+      rr(std::integral_constant<int, (r % NRR) * RNP + i>{}) = *rp;
     });
   };
 
@@ -422,7 +438,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
           if constexpr (i % 4 == 3) {
             u4* gp = reinterpret_cast<u4*>(yprev + (size_t)cc * (32 * kC * 2) + (i / 4) * 4096 + tg);
             if (DBG & 128) __builtin_nontemporal_store(treg, gp);      // (timing variant)
-            else *gp = treg;
+            else c16_store(gp, treg, pol);
           }
         }
         if (last && RES != 0 && !(DBG & 1) && mi == 2 * RB - 2) {  // the first passes' residual, spread over the last chunk
@@ -555,7 +571,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
     for (int r = 0; r < W2_RB; ++r)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<u4*>(yprev + (size_t)r * (32 * kC * 2) + i * 4096 + tg) = *reinterpret_cast<const u4*>(outw + r * 16384 + tl[i]);
+        c16_store(reinterpret_cast<u4*>(yprev + (size_t)r * (32 * kC * 2) + i * 4096 + tg), *reinterpret_cast<const u4*>(outw + r * 16384 + tl[i]), pol);
   }
 }
 
@@ -835,6 +851,12 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   }
   const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
   static const bool zb = getenv("AGZ_C16_DM") && atoi(getenv("AGZ_C16_DM")) != 0;
+  static bool policy_set = false;
+  if (!policy_set) {
+    policy_set = true;
+    const unsigned pm = getenv("AGZ_C16_POLICY") ? (unsigned)strtoul(getenv("AGZ_C16_POLICY"), nullptr, 0) : 0u;
+    if (pm) AGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_c16_policy), &pm, sizeof(pm)));
+  }
 #define AGZ_C16_W2(D, R, OF, RB, G)                                                                                                      \
   do {                                                                                                                                   \
     if (zb && (D) == 0)                                                                                                                  \
