@@ -550,6 +550,7 @@ struct GameRecord
   qs::Vector{Float32}
   result::Int
   result_string::String
+  short_searches::Int                    # moves played on fewer than num_ro readouts (full node pool, agz_config.pool_policy); 0 = the reference's game
 end
 
 function selfplay(env::GoEnv, nn::NeuralNet, num_ro::Int = 800; games::Int = 1, slots::Int = min(games, 1024),
@@ -575,7 +576,7 @@ function selfplay(env::GoEnv, nn::NeuralNet, num_ro::Int = 800; games::Int = 1, 
          h[].final_score > 0 ? "B+$(round(h[].final_score, digits = 1))" :
          h[].final_score < 0 ? "W+$(round(-h[].final_score, digits = 1))" : "DRAW"
     push!(recs, GameRecord(h[].game_id, Int.(moves[1:n]) .+ 1, [pis[:, i] for i in 1:n], qs[1:n],
-                           Int(h[].result), rs))
+                           Int(h[].result), rs, Int(h[].short_searches)))
   end
   sort!(recs, by = r -> r.game_id)
   games == 1 ? recs[1] : recs
