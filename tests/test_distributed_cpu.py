@@ -259,3 +259,23 @@ def test_hosted_exchange_of_nothing_and_failure_sentinel():
     got = run_hosted([(2, 128), (1, 64)], fail_rank=0)
     assert got[0]["error"][0] == ag._lib.HIP_ERROR                       # the failing rank reports its own failure
     assert got[1]["error"][0] == ag._lib.RCCL_ERROR and "rank 0 failed before the exchange" in got[1]["error"][1]
+
+
+def test_bench_self_launcher_starts_n_ranks_and_propagates_their_status():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset is its own launcher.  Without a GPU every rank must
+    stop at the same place with the same message -- 'no CPU fallback' -- and the launcher must return their status; with
+    --gpus above the visible device count (and no --single-device-test) it refuses before starting anything."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the GPU suite runs the launcher for real (tests/test_gpu_multirank.py)")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-device-test", "--steps", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 1 and r.stdout.strip() == ""
+    assert r.stderr.count("bench.py needs an MI355X: the engine has no CPU fallback") == 2, r.stderr[-500:]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 2 and "--gpus 2 but 0 GPU(s) visible" in r.stderr
