@@ -123,7 +123,8 @@ __device__ unsigned g_c16_pace = 0;
 
 // Cache policy of the result stores / residual loads of the trickled epilogue, set once from AGZ_C16_POLICY (round 5
 // experiment, HISTORY.md 12): bits 0-1 = stores plain / sc1 (write-through: the line does not stay in this XCD's L2, where
-// it would push the 1.2 MB of weights every tile re-reads out) / nt / sc0 sc1.  (A second switch on the residual loads
+// it would push the 1.2 MB of weights every tile re-reads out) / nt / sc0 sc1; bits 3 / 4 (measurement only, WRONG
+// results): drop the trickled result stores of every other workgroup / of all.  (A second switch on the residual loads
 // made the residual-carrying form spill 25 registers: this kernel has no register to give.)
 __device__ unsigned g_c16_policy = 0;
 typedef unsigned c16_u4 __attribute__((ext_vector_type(4)));
@@ -159,7 +160,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // base register plus an immediate, and seven address registers go away.  (The first form of this, a 256-byte zero block
 // read at the real address modulo 256, removed the conflicts too and cost 16-18 spilled registers, each reload a
 // vmcnt(0) behind 17 k-steps of weight loads in flight: +4.7 % cycles, profiles/r05_c16_zb_*.)
-template <int DBG, int RES, bool OUTF, int RB, bool WL, bool DM>
+// MEAS (round 5, AGZ_C16_MEAS=<mask>; measurement only, results WRONG): parts of the tile loop compiled out WITHOUT changing
+// what the MFMAs multiply -- 32: the weight fragments of one full ring fill are reused (no re-loads), 64: the slabs of chunks 0
+// and 1 are reused (no further slab DMA), 128: the slab fragments read for the first k-step are reused (no LDS operand
+// reads), 256: no epilogue arithmetic.  (The result stores are dropped at run time: AGZ_C16_POLICY bits 3 / 4.)  Round 4's
+// variants (DBG) left activation buffers unwritten or operand registers constant: their MFMAs multiplied zeros or constants,
+// and a matrix pipe's power follows its operands (HISTORY.md 12).
+template <int DBG, int RES, bool OUTF, int RB, bool WL, bool DM, int MEAS = 0>
 __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const void* __restrict__ res, void* __restrict__ y,
@@ -318,6 +325,8 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   u4 treg = {0, 0, 0, 0};
   const unsigned pol = __builtin_amdgcn_readfirstlane(g_c16_policy);
+  // (measurement only, results WRONG: bit 3 = the result stores of every other workgroup are dropped, bit 4 = of all)
+  const unsigned drop = 16u | ((blockIdx.x & 1u) ? 8u : 0u);
   char* yprev = nullptr;                                  // tile whose image is leaving: base of its rows in y
 
   int tile = blockIdx.x;
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
 #pragma unroll
   for (int j = 0; j < NPJ; ++j) dma_a(0, 0, j);
 #pragma unroll
-  for (int k = 0; k < W2_D; ++k) load_b(WL ? k % WD : k, wfw, k);
+  for (int k = 0; k < ((MEAS & 32) ? W2_RING : W2_D); ++k) load_b(WL ? k % WD : k, wfw, k);
   if (DBG & (2 | 512)) {      // (timing variants without weight loads into registers: operands that toggle like real ones)
 #pragma unroll
     for (int sl = 0; sl < W2_RING; ++sl)
@@ -419,8 +428,8 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
           acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bf[slot][cb], A[rbk], acc[rbk][cb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (cb == 1 && (i < 17 || !last) && !(DBG & 4)) read_a(nks, rbk);
-        if (mi == 2 && !(DBG & 2)) load_b(WL ? (i + W2_D) % WD : (i + W2_D) % W2_RING, wb, kn);
+        if (cb == 1 && (i < 17 || !last) && !(DBG & 4) && !(MEAS & 128)) read_a(nks, rbk);
+        if (mi == 2 && !(DBG & 2) && !(MEAS & 32)) load_b(WL ? (i + W2_D) % WD : (i + W2_D) % W2_RING, wb, kn);
         if (WL && mi == 8 && !(DBG & 2)) {
           // k-step i + 1's fragments: fetched WD - 2 k-steps ago; the 2 (WD - 2) pieces issued since may be in flight
           // (anything else issued since -- slab pieces, residual loads -- only makes this wait a little longer)
@@ -430,7 +439,8 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
         // the next chunk's slab (the next tile's first, in the last chunk) goes out in k-steps 0 and 1
         // (after the last tile the spare buffer just receives the first slab once more: no branch in the loop)
         if (!(DBG & 8)) {
-          if (i < 2 && mi >= 3 && mi < 6 && i * 3 + mi - 3 < NPJ) dma_a(last ? 0 : cc + 1, sbuf ^ 1, i * 3 + mi - 3);
+          if (i < 2 && mi >= 3 && mi < 6 && i * 3 + mi - 3 < NPJ && (!(MEAS & 64) || first))
+            dma_a(last ? 0 : cc + 1, sbuf ^ 1, i * 3 + mi - 3);
         }
         // chunk cc sends pass cc of the previous tile's image on its way: piece i / 4, read one k-step before it is stored
         if (TRICKLE && !last && !(DBG & 33) && mi == 12) {
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
           if constexpr (i % 4 == 3) {
             u4* gp = reinterpret_cast<u4*>(yprev + (size_t)cc * (32 * kC * 2) + (i / 4) * 4096 + tg);
             if (DBG & 128) __builtin_nontemporal_store(treg, gp);      // (timing variant)
-            else c16_store(gp, treg, pol);
+            else if (!(pol & drop)) c16_store(gp, treg, pol);
           }
         }
         if (last && RES != 0 && !(DBG & 1) && mi == 2 * RB - 2) {  // the first passes' residual, spread over the last chunk
@@ -473,6 +483,13 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
 #pragma unroll
       for (int a = 0; a < W2_RB; ++a) keep += acc[a][0][0] + acc[a][1][15];
       if (keep == 123.456f) reinterpret_cast<float*>(y)[0] = keep;
+    } else if (TRICKLE && (MEAS & 256)) {
+      float keep = 0.f;                                     // (the accumulators stay live; nothing else happens)
+#pragma unroll
+      for (int a = 0; a < W2_RB; ++a) keep += acc[a][0][0] + acc[a][1][15];
+      if (keep == 123.456f) reinterpret_cast<float*>(y)[0] = keep;
+      yprev = reinterpret_cast<char*>(y) + (size_t)m0 * (kC * 2);
+      __syncthreads();
     } else if (TRICKLE) {
       // compute only: results (and before them the residual) live in this wave's image, the stores ride on the next tile
       auto pass = [&](auto rc) __attribute__((always_inline)) {
@@ -840,7 +857,28 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   const _Float16* xh = (const _Float16*)x;
   static int ncu = 0;
   if (!ncu) AGZ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+  static const int meas = getenv("AGZ_C16_MEAS") ? atoi(getenv("AGZ_C16_MEAS")) : 0;
+  static bool policy_set = false;
+  if (!policy_set) {
+    policy_set = true;
+    const unsigned pm = getenv("AGZ_C16_POLICY") ? (unsigned)strtoul(getenv("AGZ_C16_POLICY"), nullptr, 0) : 0u;
+    if (pm) AGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_c16_policy), &pm, sizeof(pm)));
+  }
   const int rk = !res ? 0 : (res_f32 ? 2 : 1);
+  if (meas && rk == 0 && !out_f32) {      // (measurement form of the no-residual layer: tools/c16_meas.sh)
+    const int g7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
+#define AGZ_C16_MEAS_LAUNCH(MASK)                                                                                                    \
+  hipLaunchKernelGGL((k_conv3x3_f16_w2<0, 0, false, W2_RB_PRODUCT, false, false, MASK>), dim3(g7), dim3(256), 0, s, xh, wi, scale, shift, res, \
+                     y, d_count, N, relu)
+    switch (meas) {
+      case 32: AGZ_C16_MEAS_LAUNCH(32); return;
+      case 96: AGZ_C16_MEAS_LAUNCH(96); return;
+      case 224: AGZ_C16_MEAS_LAUNCH(224); return;
+      case 480: AGZ_C16_MEAS_LAUNCH(480); return;
+      default: break;           // (any other value: the product form)
+    }
+#undef AGZ_C16_MEAS_LAUNCH
+  }
   // AGZ_C16_Q=1: half-in / half-out layers on the 2 x 2 form (k_conv3x3_f16_q); the f32-residual / f32-output layers stay here
   static const bool quad = getenv("AGZ_C16_Q") && atoi(getenv("AGZ_C16_Q")) != 0;
   if (quad && !res_f32 && !out_f32) {
@@ -851,12 +889,6 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   }
   const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
   static const bool zb = getenv("AGZ_C16_DM") && atoi(getenv("AGZ_C16_DM")) != 0;
-  static bool policy_set = false;
-  if (!policy_set) {
-    policy_set = true;
-    const unsigned pm = getenv("AGZ_C16_POLICY") ? (unsigned)strtoul(getenv("AGZ_C16_POLICY"), nullptr, 0) : 0u;
-    if (pm) AGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_c16_policy), &pm, sizeof(pm)));
-  }
 #define AGZ_C16_W2(D, R, OF, RB, G)                                                                                                      \
   do {                                                                                                                                   \
     if (zb && (D) == 0)                                                                                                                  \
