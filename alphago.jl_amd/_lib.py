@@ -198,6 +198,7 @@ def load():
         "agz_debug_live_record": (i32, [E, i32, i32, P(u64), i32p, i32p, f32p, f32p]),
         "agz_debug_mfma_sustained": (i32, [E, i32, C.POINTER(C.c_float)]),
         "agz_debug_pack_diff": (i32, [E, i32, P(i64)]),
+        "agz_debug_mfma_sustained_data": (i32, [E, i32, i32, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

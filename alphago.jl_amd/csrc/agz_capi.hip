@@ -581,6 +581,9 @@ agz_status agz_debug_set_stagger(agz_engine* e, int32_t moves) {
 agz_status agz_debug_mfma_sustained(agz_engine* e, int32_t millis, float* tflops_out) {
   return guard(e, [&](agz::Engine& E) { *tflops_out = E.net().mfma_sustained_tflops(millis); });
 }
+agz_status agz_debug_mfma_sustained_data(agz_engine* e, int32_t millis, int32_t mode, float* tflops_out) {
+  return guard(e, [&](agz::Engine& E) { *tflops_out = E.net().mfma_sustained_tflops(millis, mode); });
+}
 agz_status agz_debug_pack_diff(agz_engine* e, int32_t which, int64_t* mismatches_out) {
   return guard(e, [&](agz::Engine& E) { *mismatches_out = (int64_t)E.net().debug_pack_diff(which); });
 }

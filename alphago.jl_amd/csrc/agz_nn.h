@@ -90,7 +90,7 @@ class Net {
 
   // what this board sustains on nothing but independent v_mfma_f32_32x32x2_f32 (one launch of ~10 ms after another for
   // `millis`, the median of the second half): the power-limited f32 MFMA rate bench.py quotes next to the nominal peak
-  float mfma_sustained_tflops(int millis);
+  float mfma_sustained_tflops(int millis, int mode = 0);
   // HIP-event timing of every tower-conv launch inside forward() (bench.py roofline leg)
   void profile_enable(bool on);
   void profile_read(double* total_ms, double* total_flop, int64_t* launches);

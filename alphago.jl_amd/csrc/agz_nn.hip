@@ -1079,20 +1079,70 @@ __global__ __launch_bounds__(256) void k_mfma_f32_sustained(int iters, float* ou
   if (s == 123.456f) out[0] = s;
 }
 
-float Net::mfma_sustained_tflops(int millis) {
+// The same with operands that CHANGE like a layer's do: 16 pseudo-random A and B values per lane, a different pair in front
+// of every MFMA.  A matrix pipe's power follows the toggling of its operands (MI355X_MICROARCH.md: zero-filled inputs ran
+// +19 % TF/s at the same counters; round 5 measured the fp16 tower's MFMAs alone at 0.74 ms on constants and 0.92 ms on real
+// data), so the constant-operand rate above flatters the ceiling.  F16: v_mfma_f32_32x32x16_f16 instead of the f32 MFMA.
+template <bool F16, bool DENSE>
+__global__ __launch_bounds__(256) void k_mfma_sustained_data(int iters, float* out) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  unsigned st = 0x9e3779b9u * (threadIdx.x + 256u * blockIdx.x + 1u);
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)(int)(st >> 8) * (1.0f / 8388608.0f) - 1.0f; };   // [-1, 1)
+  float a32[16], b32[16];
+  h8 a16[16], b16[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    // B like a post-ReLU activation (half of it zero: the fp16 tower's operand), or DENSE (a Winograd-transformed one)
+    a32[k] = rnd(); b32[k] = DENSE ? rnd() : fmaxf(rnd(), 0.f) * 2.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a16[k][e] = (_Float16)(0.06f * rnd());
+      b16[k][e] = (_Float16)(DENSE ? rnd() : fmaxf(rnd(), 0.f) * 2.f);
+    }
+  }
+  for (int it = 0; it < iters; it += 16) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (F16) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[(i + u) & 15], b16[(3 * i + 5 * u) & 15], acc[i], 0, 0, 0);
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a32[(i + u) & 15], b32[(3 * i + 5 * u) & 15], acc[i], 0, 0, 0);
+      }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
+  if (s == 123.456f) out[0] = s;
+}
+
+// mode 0: constant f32 operands (agz_debug_mfma_sustained); 1 / 2: changing f32 / fp16 (32x32x16) operands, B half zero;
+// 3 / 4: the same with a dense B
+float Net::mfma_sustained_tflops(int millis, int mode) {
   AGZ_REQUIRE(millis >= 50 && millis <= 5000, AGZ_BAD_ARGUMENT, "mfma_sustained_tflops: %d ms (50..5000)", millis);
+  AGZ_REQUIRE(mode >= 0 && mode <= 4, AGZ_BAD_ARGUMENT, "mfma_sustained_tflops: mode %d", mode);
+  const bool f16 = mode == 2 || mode == 4;
   DevBuf<float> out;
   out.alloc(16);
   hipEvent_t e0, e1;
   AGZ_HIP(hipEventCreate(&e0));
   AGZ_HIP(hipEventCreate(&e1));
-  const int iters = 10000, grid = 1024;      // 4 workgroups of 4 waves per CU; ~11 ms per launch
-  const double flop = (double)grid * 4 * iters * 8.0 * 4096.0;
+  const int iters = f16 ? 20000 : 10000, grid = 1024;      // 4 workgroups of 4 waves per CU; ~11 ms per launch
+  const double flop = (double)grid * 4 * iters * 8.0 * (f16 ? 32768.0 : 4096.0);
   std::vector<double> tf;
   double spent = 0.0;
   while (spent < millis) {
     AGZ_HIP(hipEventRecord(e0, stream_));
-    hipLaunchKernelGGL(k_mfma_f32_sustained, dim3(grid), dim3(256), 0, stream_, iters, out.p);
+    if (mode == 0) hipLaunchKernelGGL(k_mfma_f32_sustained, dim3(grid), dim3(256), 0, stream_, iters, out.p);
+    else if (mode == 1) hipLaunchKernelGGL((k_mfma_sustained_data<false, false>), dim3(grid), dim3(256), 0, stream_, iters, out.p);
+    else if (mode == 2) hipLaunchKernelGGL((k_mfma_sustained_data<true, false>), dim3(grid), dim3(256), 0, stream_, iters, out.p);
+    else if (mode == 3) hipLaunchKernelGGL((k_mfma_sustained_data<false, true>), dim3(grid), dim3(256), 0, stream_, iters, out.p);
+    else hipLaunchKernelGGL((k_mfma_sustained_data<true, true>), dim3(grid), dim3(256), 0, stream_, iters, out.p);
     AGZ_HIP(hipEventRecord(e1, stream_));
     AGZ_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -306,6 +306,10 @@ def shard_leg(ag, torch, name, N, tower, R, games, precision, steps, warmup, sta
         peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS
         alg = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
         pos = s1["positions"] - s0["positions"]
+        try:        # what this board sustains on MFMAs alone with changing operands, in this leg's arithmetic
+            sustained = eng.mfma_sustained_data_tflops(400, 2 if f16 else 3)      # fp16: dense weights x half-zero activations
+        except Exception:
+            sustained = None
         traffic, traffic_src = pmc_traffic(conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256), N, precision, not f16)
         return {
             "config": name, "precision": precision,
@@ -319,7 +323,10 @@ def shard_leg(ag, torch, name, N, tower, R, games, precision, steps, warmup, sta
                          "achieved": alg * ratio if alg else None, "peak": peak, "unit": "TFLOP/s",
                          "frac": alg * ratio / peak if alg else None, "achieved_algorithmic": alg,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": (1280.0 if f16 else 2560.0) * conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256)},
+                         "algorithmic_bytes_per_launch": (1280.0 if f16 else 2560.0) * conv_flop / max(conv_n, 1) / (2.0 * 9 * 256 * 256),
+                         "sustained_mfma_changing_operands": None if not (sustained and alg) else {
+                             "value": sustained, "unit": "TFLOP/s", "frac_of_nominal_peak": sustained / peak,
+                             "achieved_over_sustained": alg * ratio / sustained}},
             "end_to_end_algorithmic_tflops": pos / dt * R * f_eval(N, tower) / 1e12,
             "power": power,
             "pool": {"node_capacity": s1["node_capacity"], "peak_nodes_per_game": s1["peak_nodes_per_game"],
@@ -734,11 +741,22 @@ def main():
                 sus = eng.mfma_sustained_tflops(400)
                 roofline["sustained_mfma"] = {
                     "value": sus, "unit": "TFLOP/s", "frac_of_nominal_peak": sus / peak, "achieved_over_sustained": exe_tf / sus,
-                    "what": "v_mfma_f32_32x32x2_f32 from registers only, one launch of ~10 ms after another for 0.4 s on this "
-                            "GPU, median of the second half: the board's power limit holds the clock near 1.9 GHz",
+                    "what": "v_mfma_f32_32x32x2_f32 from registers only (two CONSTANT operands, a loop of 8 MFMAs), one launch of "
+                            "~10 ms after another for 0.4 s on this GPU, median of the second half.  Kept for continuity with "
+                            "rounds 3-4; it is bounded by its own loop (610-700 W at 2.3 GHz), not by the board: see "
+                            "sustained_mfma_changing_operands",
+                }
+                # the same with operands that change in front of every MFMA (dense pseudo-random A and B, as Winograd-transformed
+                # operands are) and a loop unrolled 16 x 8 deep: THIS is the ceiling a real layer has.  (Round 5, HISTORY.md 12:
+                # the constant-operand figure above is bounded by its own 8-MFMA loop, not by the board's power.)
+                susd = eng.mfma_sustained_data_tflops(400, 3)
+                roofline["sustained_mfma_changing_operands"] = {
+                    "value": susd, "unit": "TFLOP/s", "frac_of_nominal_peak": susd / peak, "achieved_over_sustained": exe_tf / susd,
+                    "what": "v_mfma_f32_32x32x2_f32 from registers only, every MFMA a different pair of 16 dense pseudo-random A / B "
+                            "register values per lane, 128 MFMAs per loop iteration",
                 }
             except Exception as ex:      # never at the expense of the line
-                roofline["sustained_mfma"] = {"error": f"{type(ex).__name__}: {ex}"}
+                roofline.setdefault("sustained_mfma", {"error": f"{type(ex).__name__}: {ex}"})
         out = {
             "metric": f"self-play positions/sec ({N}x{N}, tower={tower}, {R} readouts)" + (" [fp16 tower]" if f16 else "")
                       + (" [f32 as split f16 operands]" if f32s else ""),

@@ -43,6 +43,11 @@ agz_status agz_debug_live_record(agz_engine* e, int32_t g, int32_t k, uint64_t* 
  * independent v_mfma_f32_32x32x2_f32 from registers -- back-to-back ~10 ms launches for `millis` (50..5000), median of the
  * second half.  On an MI355X at its power limit: ~124, i.e. 0.79 of the nominal 157.3 (HISTORY.md 4f).  Synchronises. */
 agz_status agz_debug_mfma_sustained(agz_engine* e, int32_t millis, float* tflops_out);
+/* The same with operands that change in front of every MFMA as a layer's do (a matrix pipe's power follows its operands'
+ * toggling, and the rate above is measured on constants): mode 1 = f32 MFMA, pseudo-random A, half-zero B (post-ReLU-like);
+ * mode 2 = v_mfma_f32_32x32x16_f16 likewise; modes 3 / 4 = f32 / fp16 with a dense pseudo-random B (a Winograd-transformed
+ * operand); mode 0 = the constant-operand measurement above.  TFLOP/s. */
+agz_status agz_debug_mfma_sustained_data(agz_engine* e, int32_t millis, int32_t mode, float* tflops_out);
 /* The inference weight images are built on the device from the device master copy of the parameters (DESIGN.md "weights").
  * This hook rebuilds image family `which` on the HOST from the host copies (the round-1..4 pack code, kept as the
  * reference) and counts the 32-bit words in which the device image differs: 0 = direct Wt, 1 = F(3x3,3x3) U (+ stem),
