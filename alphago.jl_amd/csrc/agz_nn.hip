@@ -799,6 +799,11 @@ void launch_conv3x3_direct_taps(const float* x, const float* wt, const float* on
 // everything enqueued so far (fork) and that stream_ waits for afterwards (join).  With more than one chain the layers
 // overlap, so the profile keeps ONE event pair around the whole tower (2 * tower layers).  Returns whether this tower is
 // being timed.
+static int tower_chunks() {
+  static const int n = getenv("AGZ_TOWER_CHUNKS") ? atoi(getenv("AGZ_TOWER_CHUNKS")) : 0;
+  return n;
+}
+
 bool Net::fork_chains(int parts) {
   const bool pt = prof_on_ && prof_n_ < kProfMax;
   if (parts <= 1) return pt;
@@ -921,11 +926,14 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         // per chain); the chains touch disjoint rows of the same buffers.
         // (a chain should still fill the chip a few times over: at least ~4 workgroup rounds = 256 tile blocks each)
         const long tblocks = ((long)bcap * ((N_ + 3) / 4) * ((N_ + 3) / 4) + 63) / 64;
-        const int parts = (int)std::max<long>(1, std::min<long>(tower_streams_, tblocks / 256));
-        const bool pt = fork_chains(parts);
+        const int nst = (int)std::max<long>(1, std::min<long>(tower_streams_, tblocks / 256));
+        // (experiment, AGZ_TOWER_CHUNKS: more ranges than streams -- a stream runs its ranges one after the other, each through
+        // all layers, so that a range's V might stay in the Infinity Cache between consecutive layers; HISTORY.md 12)
+        const int parts = nst <= 1 ? 1 : (int)std::max<long>(nst, std::min<long>(tower_chunks(), tblocks / 64));
+        const bool pt = fork_chains(nst);
         try {                          // (a launcher that throws must not leave the side streams un-joined: ADVICE r4)
         for (int part = 0; part < parts; ++part) {
-          hipStream_t st = part == 0 ? stream_ : streamx_[part - 1];
+          hipStream_t st = part % nst == 0 ? stream_ : streamx_[part % nst - 1];
           float *pa = a, *pb = b, *vc = vcur, *vn = vnxt;
           for (int blk = 0; blk < tower_; ++blk) {
             const int l1 = 2 * blk, l2 = 2 * blk + 1;
@@ -947,10 +955,10 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
           }
         }
         } catch (...) {
-          join_chains(parts, pt);
+          join_chains(nst, pt);
           throw;
         }
-        join_chains(parts, pt);
+        join_chains(nst, pt);
         if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
       } else {
       if (stem_wino) {
@@ -1002,11 +1010,12 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
       // sweep (tools/chains_sweep.sh): 46.8 / 47.7 with one, 46.4 / 46.6 with two, 46.6 / 46.8 with three, 47.0 / 47.0 with four.
       const int chains33 = tower_streams_;
       const long tblocks3 = ((long)bcap * ((N_ + 2) / 3) * ((N_ + 2) / 3) + 62) / 63;
-      const int parts = dense ? 1 : (int)std::max<long>(1, std::min<long>(std::min(chains33, (int)kMaxTowerStreams), tblocks3 / 256));
-      const bool pt = fork_chains(parts);
+      const int nst = dense ? 1 : (int)std::max<long>(1, std::min<long>(std::min(chains33, (int)kMaxTowerStreams), tblocks3 / 256));
+      const int parts = nst <= 1 ? 1 : (int)std::max<long>(nst, std::min<long>(tower_chunks(), tblocks3 / 64));
+      const bool pt = fork_chains(nst);
       try {
       for (int part = 0; part < parts; ++part) {
-        hipStream_t st = part == 0 ? stream_ : streamx_[part - 1];
+        hipStream_t st = part % nst == 0 ? stream_ : streamx_[part % nst - 1];
         float *pa = a, *pb = b;
         for (int blk = 0; blk < tower_; ++blk) {
           const int l1 = 2 * blk, l2 = 2 * blk + 1;
@@ -1027,10 +1036,10 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
         }
       }
       } catch (...) {
-        join_chains(parts, pt);
+        join_chains(nst, pt);
         throw;
       }
-      join_chains(parts, pt);
+      join_chains(nst, pt);
       if (tower_ % 2) std::swap(a, b);               // the block outputs alternate between a and b
       }
       }
