@@ -735,7 +735,7 @@ def main():
             "algorithmic_flop_per_launch_avg": conv_flop / max(conv_n, 1),
         }
         if not f16 and not f32s and exe_tf is not None and not args.no_sustained:
-            # context, not the contract's `peak`: what THIS board sustains on f32 MFMAs alone (power-limited clock), measured
+            # context, not the contract's `peak`: the constant-operand MFMA-only figure of rounds 3-4 (bounded by its own loop), measured
             # now, after the timed region (0.4 s of back-to-back register-only MFMA launches; HISTORY.md 4f)
             try:
                 sus = eng.mfma_sustained_tflops(400)
