@@ -15,6 +15,17 @@
 // reads per MFMA plus the DMA writes); the persistent one-wave-per-SIMD form below 0.63-0.66 ms.
 // The reduction order of an output is fixed (chunk, tap, k) and does not depend on where its row sits in the
 // batch: tree parity with the oracle (which calls this network) stays bit-exact.
+//
+// What is in this file.  THE PRODUCT is k_conv3x3_f16_w2<0, RES, OUTF, 7, false, false, 0> (six forms: residual none / half / f32,
+// output half / f32) plus the weight-image and conversion kernels.  Everything else is measurement apparatus kept so that the
+// tables in HISTORY.md 4b / 4h / 12 can be re-run on the same source, none of it reachable without an environment switch:
+//   AGZ_C16_DM=1        DM form: off-board fragments zeroed in registers (conflict-free slab reads; slower)        round 5
+//   AGZ_C16_Q=1         k_conv3x3_f16_q: 2 x 2 wave arrangement over 256 x 256 tiles (bit-identical; +0.6 %)       round 5
+//   AGZ_C16_POLICY=n    bits 0-1 cache policy of the trickled result stores; bits 3 / 4 drop them (results WRONG)   round 5
+//   AGZ_C16_MEAS=mask   valid-operand timing forms: parts of the loop compiled out, operands reused (results WRONG)  round 5
+//   -DAGZ_C16_WL=true   weights through a wave-private LDS ring                                                     round 4
+//   -DAGZ_TIMING_EXPERIMENTS + AGZ_C16_DEBUG / AGZ_C16_RB / AGZ_C16_PACE: round 2-4 timing variants (their operand data is
+//                       not preserved: superseded by MEAS, HISTORY.md 12)
 #include "agz_nn.h"
 
 #include <hip/hip_fp16.h>
