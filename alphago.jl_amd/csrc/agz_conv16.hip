@@ -16,11 +16,12 @@
 // The reduction order of an output is fixed (chunk, tap, k) and does not depend on where its row sits in the
 // batch: tree parity with the oracle (which calls this network) stays bit-exact.
 //
-// What is in this file.  THE PRODUCT is k_conv3x3_f16_w2<0, RES, OUTF, 7, false, false, 0> (six forms: residual none / half / f32,
-// output half / f32) plus the weight-image and conversion kernels.  Everything else is measurement apparatus kept so that the
+// What is in this file.  THE PRODUCT is k_conv3x3_f16_q<RES> (2 x 2 waves over 256-row x 256-cout tiles) for the half-in /
+// half-out layers, k_conv3x3_f16_w2<0, RES, OUTF, 7, false, false, 0> (7 x 2 wave tiles over 224 rows) for the f32-residual and
+// f32-output layers -- and for every layer with AGZ_C16_Q=0 -- plus the weight-image and conversion kernels.  Everything else is measurement apparatus kept so that the
 // tables in HISTORY.md 4b / 4h / 12 can be re-run on the same source, none of it reachable without an environment switch:
 //   AGZ_C16_DM=1        DM form: off-board fragments zeroed in registers (conflict-free slab reads; slower)        round 5
-//   AGZ_C16_Q=1         k_conv3x3_f16_q: 2 x 2 wave arrangement over 256 x 256 tiles (bit-identical; +0.6 %)       round 5
+//   AGZ_C16_Q=0 / 2     the 7 x 2 form for every layer / the 2 x 2 form for the no-residual layers only (A/B runs)    round 5
 //   AGZ_C16_POLICY=n    bits 0-1 cache policy of the trickled result stores; bits 3 / 4 drop them (results WRONG)   round 5
 //   AGZ_C16_MEAS=mask   valid-operand timing forms: parts of the loop compiled out, operands reused (results WRONG)  round 5
 //   -DAGZ_C16_WL=true   weights through a wave-private LDS ring                                                     round 4
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Round 5: the same convolution with the four waves of a workgroup arranged 2 x 2 over a 256-row x 256-cout tile -- a
+// Round 5 (the product for half-in / half-out layers): the same convolution with the four waves of a workgroup arranged 2 x 2 over a 256-row x 256-cout tile -- a
 // wave owns 128 rows x 128 couts (4 x 4 accumulator tiles = all 256 AGPRs) instead of 224 x 64.  Per k-step a wave then
 // reads 4 slab fragments (4 KB) and 4 weight fragments (4 KB) for 16 MFMAs, where the 7 x 2 form reads 7 + 2 for 14: the
 // LDS operand reads per row halve (16 KB per k-step and CU for 256 rows against 28 KB for 224), the two waves of a cout half
@@ -613,14 +614,17 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
 // wave-private 32 x 128 tiles (the result image of a 256-row tile does not fit beside the slabs), weight fragments 8
 // k-steps ahead through a ring of 9.  Same reduction order per output (chunk, tap, k) as the 7 x 2 form: bit-identical results.
 constexpr int QM = 256;                              // rows per tile
-template <int RES>
+// ZB (AGZ_C16_QZ=1, experiment): off-board lanes read zeros from a 256-byte zero block at their real address modulo 256 -- the
+// banks an on-board lane would use -- instead of from one shared zero row: conflict-free slab reads.
+template <int RES, bool ZB = false>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const _Float16* __restrict__ res, _Float16* __restrict__ y,
                                                          const int* __restrict__ d_count, int N, int relu) {
   constexpr int SLABCH = ((QM + 2 * 20) * 4 + 63) / 64, NPJ = (SLABCH + 3) / 4;      // 1 KB pieces of a slab (halo <= 20 rows a side)
   constexpr int SLAB = SLABCH * 512, SLABS = SLAB + 32;                              // halves; + one 64-byte row of zeros
-  constexpr int OFF_SC = 2 * SLABS, OFF_T = OFF_SC + 1024;
+  constexpr int OFF_Z = (2 * SLABS + 127) / 128 * 128;                               // ZB: 128 halves of zeros, 256-byte aligned
+  constexpr int OFF_SC = ZB ? OFF_Z + 128 : 2 * SLABS, OFF_T = OFF_SC + 1024;
   constexpr int TSB = 264, TB = 32 * TSB;                                            // epilogue tile: 32 rows x 128 halves, row stride 264 B (66 dwords: a lane = row access of 8 bytes is conflict-free)
   constexpr int SMEM = OFF_T + 4 * 2 * TB / 2;
 #ifndef AGZ_C16_QD
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
 #endif
   constexpr int D = AGZ_C16_QD, RING = D + 1;
   static_assert(SMEM * 2 <= 160 * 1024 && 18 % RING == 0, "layout");
-  __shared__ __attribute__((aligned(128))) _Float16 smem[SMEM];
+  __shared__ __attribute__((aligned(256))) _Float16 smem[SMEM];
   const int P = N * N;
   const int M = (*d_count) * P;
   const int ntiles = (M + QM - 1) / QM;
@@ -642,6 +646,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
   const int nslabch = (slab * 4 + 63) / 64;
   char* sm = reinterpret_cast<char*>(smem);
   if (tid < 8) reinterpret_cast<uint4*>(smem + (tid >> 2) * SLABS + SLAB)[tid & 3] = make_uint4(0, 0, 0, 0);
+  if (ZB && tid < 16) reinterpret_cast<uint4*>(smem + OFF_Z)[tid] = make_uint4(0, 0, 0, 0);
   {
     float* tab = reinterpret_cast<float*>(smem + OFF_SC);
     tab[tid] = scale[tid];
@@ -690,8 +695,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
     const int base = sbuf * (SLABS * 2);
     const int R0 = wr * 128 + l31 + halo + off;
     const int a0 = base + (R0 << 6) + ((((R0 >> 2) ^ hi) & 3) << 4);
+    const int z0 = ZB ? OFF_Z * 2 + (a0 & 255) : base + SLAB * 2;          // (row blocks are 2048 bytes apart: same banks)
 #pragma unroll
-    for (int rbk = 0; rbk < 4; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : base + SLAB * 2;
+    for (int rbk = 0; rbk < 4; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : z0;
   };
   auto read_a = [&](int ks, int rbk) __attribute__((always_inline)) {
     A[rbk] = *reinterpret_cast<const h8*>(sm + (aaddr[rbk] ^ (ks << 5)));
@@ -704,6 +710,18 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
   };
   char* Tin = sm + OFF_T * 2 + wave * (2 * TB);
   char* Tout = Tin + TB;
+  // residual pieces of one epilogue pass (32 rows x 256 B of this wave's cout half: 8 x 16 B per lane), fetched one pass ahead:
+  // pass 0's during the last chunk, pass r + 1's while pass r is computed.  (Scalars: hipcc moves a captured array into LDS.)
+  uint4 q0 = {}, q1 = {}, q2 = {}, q3 = {}, q4 = {}, q5 = {}, q6 = {}, q7 = {};
+  auto rload_pass = [&](int mr, int ln) __attribute__((always_inline)) {
+    auto one = [&](int i) __attribute__((always_inline)) {
+      const int pc = ln + 64 * i, row = pc >> 4, c16 = pc & 15;
+      int m = mr + row;
+      m = m < M ? m : M - 1;
+      return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(res) + ((size_t)m * kC + wc * 128) * 2 + c16 * 16);
+    };
+    q0 = one(0); q1 = one(1); q2 = one(2); q3 = one(3); q4 = one(4); q5 = one(5); q6 = one(6); q7 = one(7);
+  };
 
   int tile = blockIdx.x;
   int m0 = tile * QM;
@@ -755,6 +773,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
           }
           if (i < 17 || !last) read_a(nks, rbk);
           if (rbk == 0) load_b((i + D) % RING, wb, kn);
+          if (last && RES != 0 && i == 9 && rbk == 2) rload_pass(m0 + wr * 128, lane);
           // the next chunk's slab (the next tile's first, in the last chunk) goes out in k-steps 0 and 1
           // (after the last tile the spare buffer just receives a slab once more: no branch in the loop)
           if (i < 2 && rbk >= 1 && (i * 3 + rbk - 1) < NPJ) dma_a(last ? 0 : cc + 1, sbuf ^ 1, i * 3 + rbk - 1);
@@ -783,20 +802,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
       constexpr int r = decltype(rc)::value;
       const int mr = m0 + wr * 128 + r * 32;
       if (RES != 0) {
-        // (scalars, not an array: hipcc moves a by-reference captured array into LDS)
-        auto rload = [&](int i) __attribute__((always_inline)) {
-          const int pc = eln + 64 * i, row = pc >> 4, c16 = pc & 15;
-          int m = mr + row;
-          m = m < M ? m : M - 1;
-          return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(res) + ((size_t)m * kC + wc * 128) * 2 + c16 * 16);
-        };
         auto rput = [&](int i, uint4 v) __attribute__((always_inline)) {        // (row stride 264 B: 8-byte LDS accesses)
           const int pc = eln + 64 * i, row = pc >> 4, c16 = pc & 15;
           *reinterpret_cast<uint2*>(Tin + row * TSB + c16 * 16) = make_uint2(v.x, v.y);
           *reinterpret_cast<uint2*>(Tin + row * TSB + c16 * 16 + 8) = make_uint2(v.z, v.w);
         };
-        const uint4 r0 = rload(0), r1 = rload(1), r2 = rload(2), r3 = rload(3), r4 = rload(4), r5 = rload(5), r6 = rload(6), r7 = rload(7);
-        rput(0, r0); rput(1, r1); rput(2, r2); rput(3, r3); rput(4, r4); rput(5, r5); rput(6, r6); rput(7, r7);
+        rput(0, q0); rput(1, q1); rput(2, q2); rput(3, q3); rput(4, q4); rput(5, q5); rput(6, q6); rput(7, q7);
+        if constexpr (r + 1 < 4) rload_pass(mr + 32, eln);
       }
       asm volatile("" ::: "memory");
 #pragma unroll
@@ -891,9 +903,17 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
 #undef AGZ_C16_MEAS_LAUNCH
   }
   // AGZ_C16_Q=1: half-in / half-out layers on the 2 x 2 form (k_conv3x3_f16_q); the f32-residual / f32-output layers stay here
-  static const bool quad = getenv("AGZ_C16_Q") && atoi(getenv("AGZ_C16_Q")) != 0;
-  if (quad && !res_f32 && !out_f32) {
+  // the half-in / half-out layers (38 of a tower's 40) run on the 2 x 2 form since round 5 (-1.8 % per configs[4] step in a
+  // same-box A/B, bit-identical results); AGZ_C16_Q=0: the 7 x 2 form for every layer, 2: the 2 x 2 form for the no-residual form only
+  static const int quad = getenv("AGZ_C16_Q") ? atoi(getenv("AGZ_C16_Q")) : 1;
+  if (quad && !res_f32 && !out_f32 && (quad == 1 || !res)) {
     const int gq = std::min((int)((rows + QM - 1) / QM), ncu);
+    static const bool qz = getenv("AGZ_C16_QZ") && atoi(getenv("AGZ_C16_QZ")) != 0;
+    if (qz) {
+      if (res) hipLaunchKernelGGL((k_conv3x3_f16_q<1, true>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)res, (_Float16*)y, d_count, N, relu);
+      else hipLaunchKernelGGL((k_conv3x3_f16_q<0, true>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)nullptr, (_Float16*)y, d_count, N, relu);
+      return;
+    }
     if (res) hipLaunchKernelGGL((k_conv3x3_f16_q<1>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)res, (_Float16*)y, d_count, N, relu);
     else hipLaunchKernelGGL((k_conv3x3_f16_q<0>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)nullptr, (_Float16*)y, d_count, N, relu);
     return;

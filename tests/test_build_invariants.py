@@ -46,6 +46,11 @@ def test_fp16_tower_kernel_uses_no_scratch_in_any_product_form():
     behind all of them.  Round 5: the two direct-epilogue forms of a tower (f32 residual in / f32 out) spilled 29-44
     registers with the 18-deep weight ring and take a 9-deep one; every product form (DBG = 0, RB = 7, DM = 0) now compiles
     to at most one spilled dword (the half-in / half-out form with a residual: 8 bytes, outside its chunk loop)."""
-    sizes = {k: v for k, v in _scratch_sizes("agz_conv16.hip").items() if "k_conv3x3_f16_w2ILi0E" in k and "ELi7ELb0ELb0E" in k}
+    every = _scratch_sizes("agz_conv16.hip")
+    sizes = {k: v for k, v in every.items() if "k_conv3x3_f16_w2ILi0E" in k and "ELi7ELb0ELb0ELi0E" in k}
     assert len(sizes) == 6, sizes
     assert all(v <= 8 for v in sizes.values()), {k: v for k, v in sizes.items() if v > 8}
+    # the 2 x 2 form (half-in / half-out layers since round 5): no scratch without a residual, <= 16 bytes with one (two
+    # dwords outside its chunk loop); its weight ring is 6 deep because 9 spills 69-138 registers
+    quad = {k: v for k, v in every.items() if "k_conv3x3_f16_q" in k}
+    assert len(quad) == 2 and all(v <= 16 for v in quad.values()), quad
