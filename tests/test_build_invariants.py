@@ -52,5 +52,5 @@ def test_fp16_tower_kernel_uses_no_scratch_in_any_product_form():
     assert all(v <= 8 for v in sizes.values()), {k: v for k, v in sizes.items() if v > 8}
     # the 2 x 2 form (half-in / half-out layers since round 5): no scratch without a residual, <= 16 bytes with one (two
     # dwords outside its chunk loop); its weight ring is 6 deep because 9 spills 69-138 registers
-    quad = {k: v for k, v in every.items() if "k_conv3x3_f16_q" in k}
+    quad = {k: v for k, v in every.items() if "k_conv3x3_f16_q" in k and "ELb0EEEv" in k}      # (ZB = false: the product forms)
     assert len(quad) == 2 and all(v <= 16 for v in quad.values()), quad
