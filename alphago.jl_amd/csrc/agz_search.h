@@ -1066,7 +1066,9 @@ AGZ_FN void game_select_phase(W& w, const View& V, Scratch& S, int g, int par, b
   GameState& G = V.gs[g];
   int nleaves = 0, failsafe = 0, terminal = 0;
   const float n_before = G.rootN;
-  if (w.leader()) G.npend = 0;
+  // (G.err says what THIS select phase ran into: a refused allocation of an earlier phase must not shorten a later search --
+  // the tree may have been re-rooted, or its garbage released, since)
+  if (w.leader()) { G.npend = 0; G.err = 0; }
   w.sync();
   while (nleaves < par && failsafe < 2 * par) {
     failsafe++;
