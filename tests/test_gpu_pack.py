@@ -92,3 +92,19 @@ def test_set_weights_writes_through_to_the_device_master():
     p2, _ = eng.forward_features(feats)
     assert p2.tobytes() == p0.tobytes()
     eng.close()
+
+
+def test_mfma_sustained_microbenchmarks_run_and_are_ordered_as_the_hardware_says():
+    """agz_debug_mfma_sustained / _data (bench.py's `sustained_mfma*` context figures): every mode runs; the f32 pipe with
+    changing operands is at >= 0.9 of its 157.3 TFLOP/s nominal rate (it is not power-limited on MFMAs alone), the fp16
+    pipe is not (power-limited well below 2.5 PFLOP/s) and a dense B costs it more than a half-zero one"""
+    eng = ag.Engine(board_size=5, games=1, tower_height=1, num_readouts=8, max_nodes_per_game=16)
+    const = eng.mfma_sustained_tflops(100)
+    f32_sparse, f32_dense = eng.mfma_sustained_data_tflops(100, 1), eng.mfma_sustained_data_tflops(100, 3)
+    f16_sparse, f16_dense = eng.mfma_sustained_data_tflops(200, 2), eng.mfma_sustained_data_tflops(200, 4)
+    print(f"sustained TFLOP/s: f32 const {const:.1f}, f32 {f32_sparse:.1f} / {f32_dense:.1f}, fp16 {f16_sparse:.0f} / {f16_dense:.0f}")
+    assert 60 < const < 160 and f32_dense > 0.9 * 157.3 and f32_sparse > 0.9 * 157.3
+    assert 900 < f16_dense <= f16_sparse * 1.02 < 2500
+    with pytest.raises(ag.AgzError):
+        eng.mfma_sustained_data_tflops(100, 9)
+    eng.close()
