@@ -7,14 +7,15 @@ Julia call surface over the C ABI of include/agz.h."""
 from . import _lib
 from ._lib import AgzError, IllegalMove, load
 from .engine import Engine, comm_unique_id
-from .api import (BLACK, EMPTY, WHITE, GameRecord, GoEnv, MCTSPlayer, NeuralNet, PlayerMove, Position,
-                  evaluate, extract_data, from_flat, from_kgs, from_sgf, get_feats, load_model, save_model, selfplay, to_flat,
+from .api import (BLACK, EMPTY, WHITE, GameRecord, GoEnv, LeafPosition, MCTSPlayer, Momentum, NeuralNet, PlayerMove,
+                  Position, SelfPlayPlayer, _train, evaluate, extract_data, get_replay_batch, seed, from_flat, from_kgs, from_sgf, get_feats, load_model, save_model, selfplay, to_flat,
                   to_kgs, to_sgf)
 from . import bson_weights
 from . import distributed
 from .replay import ReplayBuffer
 
 __all__ = ["Engine", "comm_unique_id", "AgzError", "IllegalMove", "load", "_lib", "GoEnv", "Position", "PlayerMove", "NeuralNet",
-           "MCTSPlayer", "selfplay", "extract_data", "GameRecord", "get_feats", "to_flat", "from_flat",
+           "MCTSPlayer", "selfplay", "extract_data", "GameRecord", "SelfPlayPlayer", "LeafPosition", "get_replay_batch",
+           "Momentum", "_train", "seed", "get_feats", "to_flat", "from_flat",
            "from_kgs", "to_kgs", "from_sgf", "to_sgf", "BLACK", "WHITE", "EMPTY", "load_model", "save_model", "evaluate",
            "bson_weights", "ReplayBuffer"]

@@ -42,7 +42,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "steps", "positions", "games_started", "games_finished", "evals", "duplicate_evals",
         "terminal_visits", "root_visits", "nodes_in_use", "pool_exhausted", "resigned_games", "live_games",
-        "records_dropped", "pool_short_searches", "peak_nodes_per_game", "stalled_games", "node_capacity")]
+        "records_dropped", "pool_short_searches", "peak_nodes_per_game", "stalled_games", "node_capacity",
+        "abandoned_games")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -176,6 +177,7 @@ def load():
         "agz_tree_search": (i32, [E, i32, i32, i32p]),
         "agz_tree_search_select": (i32, [E, i32, i32, i32p]),
         "agz_tree_leaf_features": (i32, [E, i32, f32p]),
+        "agz_tree_leaf_positions": (i32, [E, i32, i32p, i8p, i8p, i32p, i8p, P(PositionInfo)]),
         "agz_tree_search_incorporate": (i32, [E, i32, f32p, f32p]),
         "agz_tree_pick_move": (i32, [E, i32, i32p]),
         "agz_tree_play_move": (i32, [E, i32, i32, i32p]),

@@ -217,12 +217,42 @@ def get_feats(pos):                           # features.jl:24-26 -> [17, N, N] 
     return f.reshape(17, N, N).transpose(0, 2, 1).copy()
 
 
-class LeafView:
-    """what a duck-typed network receives per leaf: the 17 planes and the colour to play"""
+class LeafPosition(Position):
+    """One element of the `Vector{Position}` a duck-typed network receives (`mcts_player.network([leaf.position for leaf
+    in leaves])`, mcts_play.jl:89): the leaf's GoPosition fields materialised from the device tree by
+    agz_tree_leaf_positions -- board, board_deltas (newest first), to_play, n, ko, caps, the last two moves -- so that
+    `len(positions)` is the batch size (DummyNet, test/test_mcts_player.jl:25-32) and get_feats(position) /
+    NeuralNet(positions) work on it like on any Position.  `.node` is the leaf's handle; `.feats` the 17 planes
+    (plane-major, p = row + N*col), computed on demand by agz_features."""
 
-    def __init__(self, feats, N):
-        self.feats = feats
-        self.to_play = int(feats[16 * N * N])
+    node = None
+
+    @property
+    def feats(self):
+        b, d, k, tp = self.soa()
+        return _rules_engine(self.env.N).features(b[None], d[None], [k], [tp])[0].reshape(-1)
+
+
+LeafView = LeafPosition       # round <= 5 name
+
+
+def _leaf_positions(player, lp):
+    env, N = player.env, player.env.N
+    out = []
+    for k in range(len(lp["nodes"])):
+        i = lp["info"][k]
+        nd = int(lp["ndeltas"][k])
+        recent = []
+        if i.prev_move >= 0:
+            recent.append(PlayerMove(int(i.to_play), from_flat(int(i.prev_move), env)))
+        if i.last_move >= 0:
+            recent.append(PlayerMove(-int(i.to_play), from_flat(int(i.last_move), env)))
+        pos = LeafPosition(env, lp["boards"][k].reshape(N, N).T, int(i.n), i.komi, (int(i.caps_black), int(i.caps_white)),
+                           None if i.ko < 0 else from_flat(int(i.ko), env), recent,
+                           lp["deltas"][k, :nd].reshape(nd, N, N).transpose(0, 2, 1), int(i.to_play))
+        pos.node = NodeView(player, int(lp["nodes"][k]))
+        out.append(pos)
+    return out
 
 
 class NodeView:
@@ -304,13 +334,29 @@ class NodeView:
         pos = Position(self._p.env, board, info.pos.n, info.pos.komi, (info.pos.caps_black, info.pos.caps_white),
                        None if info.pos.ko < 0 else from_flat(info.pos.ko, self._p.env), to_play=info.pos.to_play)
         pos.done = bool(info.done)
+        # `recent`: the whole move list when this node is the player's root (what extract_data / replay_position need,
+        # board.jl:557-578); for any other node the moves played since the root, behind the root's
+        moves, node, inf = [], self.id, info
+        while inf.parent >= 0:
+            moves.append(inf.fmove)
+            node = inf.parent
+            inf = self._p.engine.node_info(0, node)
+        base = getattr(self._p, "_recent", None)
+        if base is not None and node == self._p.engine.tree_root(0):
+            rec, tp = list(base), -info.pos.to_play if len(moves) % 2 else info.pos.to_play
+            for a in reversed(moves):
+                rec.append(PlayerMove(tp, from_flat(int(a), self._p.env)))
+                tp = -tp
+            pos.recent = rec
         return pos
 
 
 class MCTSPlayer:
     """MCTSPlayer(env, network; num_readouts, two_player_mode, resign_threshold), mcts_play.jl:3-24.
-    `network` is any callable positions -> (pi A x B, v B); a NeuralNet of this package is evaluated
-    on the device, anything else receives LeafView objects."""
+    `network` is any callable positions -> (pi A x B, v B) (the duck-typed field of mcts_play.jl:5): a NeuralNet of this
+    package is evaluated on the device; anything else receives a list of B Position objects (LeafPosition) exactly as
+    the reference's `mcts_player.network([leaf.position for leaf in leaves])` (mcts_play.jl:89) and may answer with
+    plain arrays or Tracker-style objects carrying `.data` (mcts_play.jl:90)."""
 
     def __init__(self, env, network, num_readouts=800, two_player_mode=False, resign_threshold=-0.9, seed=0,
                  game_id=0):
@@ -347,21 +393,31 @@ class MCTSPlayer:
         self.result, self.result_string = 0, ""
         self._start = pos
         self._moves = []
+        self._recent = list(pos.recent)
 
     @property
     def root(self):
         return NodeView(self, self.engine.tree_root(0))
 
-    def _net_on_feats(self, feats):
-        N = self.env.N
-        pi, v = self.network([LeafView(f, N) for f in feats])
-        pi = np.asarray(getattr(pi, "data", pi), np.float32)
-        v = np.asarray(getattr(v, "data", v), np.float32).reshape(-1)
-        return np.ascontiguousarray(pi.T), v       # the reference returns A x B
-
-    def tree_search(self, parallel_readouts=8):    # mcts_play.jl:73-98
-        internal = isinstance(self.network, NeuralNet)
-        return self.engine.tree_search(0, parallel_readouts, None if internal else self._net_on_feats)
+    def tree_search(self, parallel_readouts=8):    # mcts_play.jl:73-98; returns the leaves like the reference
+        e = self.engine
+        n = e.tree_search_select(0, parallel_readouts)
+        if isinstance(self.network, NeuralNet):
+            nodes = e.tree_leaf_positions(0, n, nodes_only=True)["nodes"]
+            e.tree_search_incorporate(0)
+            return [NodeView(self, int(i)) for i in nodes]
+        if n == 0:
+            e.tree_search_incorporate(0)
+            return []
+        positions = _leaf_positions(self, e.tree_leaf_positions(0, n))
+        move_probs, values = self.network(positions)             # mcts_play.jl:89
+        move_probs = np.asarray(getattr(move_probs, "data", move_probs), np.float32)      # :90
+        values = np.asarray(getattr(values, "data", values), np.float32).reshape(-1)
+        if move_probs.shape != (self.env.action_space, n) or values.shape != (n,):
+            raise AssertionError(f"network returned {move_probs.shape} / {values.shape} for {n} positions "
+                                 f"(expected ({self.env.action_space}, {n}) / ({n},))")      # mcts.jl:190
+        e.tree_search_incorporate(0, np.ascontiguousarray(move_probs.T), values)          # column i = leaf i (:91)
+        return [p.node for p in positions]
 
     def pick_move(self):                      # mcts_play.jl:52-71
         st, a = self.engine.pick_move(0)
@@ -388,6 +444,7 @@ class MCTSPlayer:
             self.qs.pop()
             return False
         self._moves.append(c)
+        self._recent.append(PlayerMove(info.pos.to_play, c))
         return True
 
     def get_position(self):                   # mcts_play.jl:141-142
@@ -419,19 +476,106 @@ class MCTSPlayer:
         return positions, [p.copy() for p in self.searches_pi], [self.result] * len(positions)
 
 
-# short_searches: moves of the game played on fewer than num_ro readouts because its node pool was full (0 = the game is
-# the reference's game; agz_config.pool_policy, include/agz.h)
+# A bare finished-game tuple (what records look like before they are wrapped; tests and the replay buffer build them by
+# hand).  short_searches: moves played on fewer than num_ro readouts because the node pool was full (0 = the game is the
+# reference's game; agz_config.pool_policy, include/agz.h)
 GameRecord = namedtuple("GameRecord", "game_id moves searches_pi qs result result_string was_resign short_searches",
                         defaults=[0])
 
 
-def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, precision="f32", **cfg):
-    """selfplay(env, nn, num_ro) (src/selfplay.jl:1-45) for `games` concurrent games on the device.
-    Returns one GameRecord per game, ordered by game id.  precision="f16" plays with the fp16-operand
-    tower (mixed-precision inference); the default is the exact f32 network."""
+class _FinishedRoot:
+    """`player.root` of a finished self-play game: the one thing train() reads from it is `.position`
+    (train.jl:72: player.root.position.n; mcts_play.jl:127,132: extract_data replays root.position.recent)"""
+
+    def __init__(self, player):
+        self._player = player
+
+    @property
+    def position(self):
+        return self._player._replay()[1]
+
+
+class SelfPlayPlayer:
+    """What `selfplay(env, nn, num_ro)` returns (selfplay.jl:44): the MCTSPlayer of ONE finished game, read-only --
+    `.result`, `.result_string`, `.qs`, `.searches_pi` (mcts_play.jl:3-15) as the device recorded them,
+    `.root.position` (the final GoPosition with its whole `recent` list: `.n`, `.board`, `.caps`, ...) and
+    `extract_data(player)`.  The tree itself stayed on the device and was recycled with its slot.  Also carries the
+    record's fields (`game_id`, `moves` as board coordinates / None, `was_resign`, `short_searches`)."""
+
+    def __init__(self, env, network, num_readouts, rec):
+        self.env, self.network, self.num_readouts = env, network, num_readouts
+        self.two_player_mode = False
+        self.tau_threshold = (env.N * env.N // 12) // 2 * 2
+        self.game_id = int(rec["game_id"])
+        self.resign_threshold = -1.0 if rec.get("resign_disabled") else -0.9       # selfplay.jl:9
+        self.moves = [from_flat(int(a), env) for a in rec["moves"]]
+        self.searches_pi = [np.array(p, np.float32) for p in rec["pis"]]
+        self.qs = np.array(rec["qs"], np.float32)
+        self.result = int(rec["result"])
+        self.was_resign = bool(rec["was_resign"])
+        self.short_searches = int(rec.get("short_searches", 0))
+        if self.was_resign:                                                         # mcts_play.jl:100-108
+            self.result_string = "B+R" if self.result == BLACK else "W+R"
+        else:
+            sc = float(rec["final_score"])                                          # board.jl:546-555
+            self.result_string = f"B+{sc:.1f}" if sc > 0 else f"W+{-sc:.1f}" if sc < 0 else "DRAW"
+        self.root = _FinishedRoot(self)
+        self._replayed = None
+
+    def _replay(self):
+        """replay_position (board.jl:557-578): the positions before each move and the final one, by agz_go_play"""
+        if self._replayed is None:
+            pos, before = Position(self.env), []
+            for c in self.moves:
+                before.append(pos)
+                pos = pos.play_move(c)
+            self._replayed = (before, pos)
+        return self._replayed
+
+    @property
+    def position(self):                        # mcts_play.jl:14
+        return self.root.position
+
+    def get_position(self):                    # mcts_play.jl:141-142
+        return self.root.position
+
+    def is_done(self):                         # mcts_play.jl:120
+        return True
+
+    def extract_data(self):                    # mcts_play.jl:126-139
+        assert len(self.searches_pi) == self.root.position.n, "GoPosition history is incomplete"
+        before, _ = self._replay()
+        return list(before), [p.copy() for p in self.searches_pi], [self.result] * len(before)
+
+
+# The reference draws from Julia's global RNG (selfplay.jl:9, mcts.jl:133,235, mcts_play.jl:61,66): successive selfplay
+# calls see successive random numbers.  Here every draw is a function of (seed, game id, move, site) (include/agz_draws.h):
+# `seed(s)` is Random.seed!(s), and each selfplay call plays the next unused game ids of that stream.
+_stream = {"seed": 0, "next_game": 0}
+
+
+def seed(s):
+    """Random.seed!(s) for selfplay(): restarts the game-id stream at 0 under draw-stream seed `s`"""
+    _stream["seed"], _stream["next_game"] = int(s), 0
+
+
+def selfplay(env, nn, num_ro=800, games=None, seed=None, slots=None, precision="f32", game_id_base=None, **cfg):
+    """selfplay(env, nn, num_ro) (src/selfplay.jl:1-45) -> the finished game's player (SelfPlayPlayer), exactly the
+    call train() makes (train.jl:57).  `games=G` (ours) plays G games concurrently on the device and returns a list of
+    G such players ordered by game id.  Game ids continue from the previous call (module stream, `seed()`), unless
+    `seed` / `game_id_base` pin them.  precision="f16" plays with the fp16-operand tower; default exact f32."""
+    single = games is None
+    games = 1 if single else int(games)
+    if seed is None:
+        seed = _stream["seed"]
+        if game_id_base is None:
+            game_id_base = _stream["next_game"]
+            _stream["next_game"] += games
+    if game_id_base is None:
+        game_id_base = 0
     slots = min(games, 1024) if slots is None else slots
     eng = Engine(board_size=env.N, tower_height=nn.tower_height, games=slots, num_readouts=num_ro, seed=seed,
-                 record_capacity_games=games + 8, **cfg)
+                 game_id_base=game_id_base, record_capacity_games=games + 8, **cfg)
     nn.engine.copy_weights_to(eng)
     eng.set_precision(precision)
     eng.start(games)
@@ -441,17 +585,9 @@ def selfplay(env, nn, num_ro=800, games=1, seed=0, slots=None, precision="f32", 
             eng.close()
             raise _lib.AgzError(_lib.POOL_EXHAUSTED, "a game is waiting on a full node pool (pool_policy = stall): raise "
                                                      "max_nodes_per_game or use the default policy")
-    out = []
-    for r in eng.records():
-        if r["was_resign"]:
-            rs = "B+R" if r["result"] == BLACK else "W+R"
-        else:
-            s = r["final_score"]
-            rs = f"B+{s:.1f}" if s > 0 else f"W+{-s:.1f}" if s < 0 else "DRAW"
-        out.append(GameRecord(r["game_id"], [from_flat(int(a), env) for a in r["moves"]], list(r["pis"]),
-                              r["qs"], r["result"], rs, bool(r["was_resign"]), int(r["short_searches"])))
+    out = [SelfPlayPlayer(env, nn, num_ro, r) for r in eng.records()]
     eng.close()
-    return out
+    return out[0] if single else out
 
 
 EvalStats = namedtuple("EvalStats", "games_won num_games win_rate resigned moves records")
@@ -496,11 +632,55 @@ def evaluate(env, black_net, white_net, num_games=400, ro=800, verbose=False, se
     return ok
 
 
-def extract_data(env, record):
-    """extract_data for a GameRecord: (positions, pis, results) with positions rebuilt by replay"""
-    pos = Position(env)
-    positions = []
+def extract_data(player, record=None):
+    """extract_data(player) -> (positions, pis, results), mcts_play.jl:126-139: one argument, the player selfplay()
+    returned or a live MCTSPlayer (train.jl:58).  The round <= 5 form extract_data(env, record) for a bare GameRecord
+    is still accepted."""
+    if record is None:
+        return player.extract_data()
+    env, pos, positions = player, Position(player), []
     for c in record.moves:
         positions.append(pos)
         pos = pos.play_move(c)
     return positions, [np.array(p) for p in record.searches_pi], [record.result] * len(positions)
+
+
+def get_replay_batch(pos_buffer, pi_buffer, res_buffer, batch_size=32, rng=None):
+    """get_replay_batch(pos_buffer, pi_buffer, res_buffer; batch_size), src/train.jl:4-12: `batch_size` distinct
+    entries (sample(..., replace=false)); pi_replay = hcat(...) is A x B.  (alphago.jl_amd.ReplayBuffer is the same
+    contract with positions kept as move lists and rebuilt on the device.)"""
+    rng = np.random.default_rng() if rng is None else rng
+    idxs = rng.choice(len(pos_buffer), size=batch_size, replace=False)
+    return ([pos_buffer[i] for i in idxs], np.stack([pi_buffer[i] for i in idxs], axis=1),
+            [res_buffer[i] for i in idxs])
+
+
+class Momentum:
+    """Flux.Momentum(eta, rho = 0.9) (train.jl:54): the state lives in the network's engine (agz_train_step)"""
+
+    def __init__(self, eta=0.01, rho=0.9):
+        self.eta, self.rho = float(eta), float(rho)
+
+
+def _train(nn, input_data, opt, epochs=1):
+    """_train(nn, (positions, pi A x B, z), opt; epochs) (src/neural_net.jl:85-101; call train.jl:70) as intended (the
+    reference's does not run at HEAD): minibatches of 32 positions (a short tail is its own batch; a single
+    left-over position joins the batch before it: BatchNorm needs two), each one agz_train_step on the device --
+    training-mode forward, 0.01 crossentropy + 0.01 mse + 1e-4 sum(theta^2), backward, Momentum update.  Returns the
+    summed minibatch loss / epochs (:98-100).  Features come from agz_features on the positions' own fields."""
+    positions, pi, z = input_data
+    pi = np.asarray(pi, np.float32)
+    z = np.asarray(z, np.float32)
+    e = nn.engine
+    soa = [p.soa() for p in positions]
+    feats = e.features(np.stack([s[0] for s in soa]), np.stack([s[1] for s in soa]), [s[2] for s in soa],
+                       [s[3] for s in soa])
+    n = len(positions)
+    cuts = list(range(0, n, 32)) + [n]
+    if len(cuts) > 2 and cuts[-1] - cuts[-2] == 1:
+        del cuts[-2]
+    loss_avg = 0.0
+    for _ in range(epochs):
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            loss_avg += float(e.train_step(feats[lo:hi], pi[:, lo:hi].T, z[lo:hi], eta=opt.eta, rho=opt.rho)[0])
+    return loss_avg / epochs

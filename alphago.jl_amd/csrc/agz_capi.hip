@@ -352,6 +352,7 @@ int32_t agz_abi_layout(const char* name, int32_t* out, int32_t cap) {
     AGZ_OFF(agz_stats, pool_exhausted); AGZ_OFF(agz_stats, resigned_games); AGZ_OFF(agz_stats, live_games);
     AGZ_OFF(agz_stats, records_dropped); AGZ_OFF(agz_stats, pool_short_searches);
     AGZ_OFF(agz_stats, peak_nodes_per_game); AGZ_OFF(agz_stats, stalled_games); AGZ_OFF(agz_stats, node_capacity);
+    AGZ_OFF(agz_stats, abandoned_games);
   } else if (n == "agz_game_header") {
     AGZ_SZ(agz_game_header);
     AGZ_OFF(agz_game_header, game_id); AGZ_OFF(agz_game_header, num_moves); AGZ_OFF(agz_game_header, result);
@@ -450,6 +451,12 @@ agz_status agz_tree_search_select(agz_engine* e, int32_t g, int32_t par, int32_t
 }
 agz_status agz_tree_leaf_features(agz_engine* e, int32_t g, float* feats_out) {
   return guard(e, [&](agz::Engine& E) { E.tree_leaf_features(g, feats_out); });
+}
+agz_status agz_tree_leaf_positions(agz_engine* e, int32_t g, int32_t* nodes_out, int8_t* boards_out, int8_t* deltas_out,
+                                   int32_t* ndeltas_out, int8_t* to_play_out, agz_position_info* info_out) {
+  return guard(e, [&](agz::Engine& E) {
+    E.tree_leaf_positions(g, nodes_out, boards_out, deltas_out, ndeltas_out, to_play_out, info_out);
+  });
 }
 agz_status agz_tree_search_incorporate(agz_engine* e, int32_t g, const float* pi, const float* v) {
   return guard_status(e, [&](agz::Engine& E) { return E.tree_search_incorporate(g, pi, v); });

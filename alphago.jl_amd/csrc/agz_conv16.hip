@@ -17,16 +17,14 @@
 // batch: tree parity with the oracle (which calls this network) stays bit-exact.
 //
 // What is in this file.  THE PRODUCT is k_conv3x3_f16_q<RES> (2 x 2 waves over 256-row x 256-cout tiles) for the half-in /
-// half-out layers, k_conv3x3_f16_w2<0, RES, OUTF, 7, false, false, 0> (7 x 2 wave tiles over 224 rows) for the f32-residual and
-// f32-output layers -- and for every layer with AGZ_C16_Q=0 -- plus the weight-image and conversion kernels.  Everything else is measurement apparatus kept so that the
-// tables in HISTORY.md 4b / 4h / 12 can be re-run on the same source, none of it reachable without an environment switch:
-//   AGZ_C16_DM=1        DM form: off-board fragments zeroed in registers (conflict-free slab reads; slower)        round 5
-//   AGZ_C16_Q=0 / 2     the 7 x 2 form for every layer / the 2 x 2 form for the no-residual layers only (A/B runs)    round 5
-//   AGZ_C16_POLICY=n    bits 0-1 cache policy of the trickled result stores; bits 3 / 4 drop them (results WRONG)   round 5
-//   AGZ_C16_MEAS=mask   valid-operand timing forms: parts of the loop compiled out, operands reused (results WRONG)  round 5
-//   -DAGZ_C16_WL=true   weights through a wave-private LDS ring                                                     round 4
-//   -DAGZ_TIMING_EXPERIMENTS + AGZ_C16_DEBUG / AGZ_C16_RB / AGZ_C16_PACE: round 2-4 timing variants (their operand data is
-//                       not preserved: superseded by MEAS, HISTORY.md 12)
+// half-out layers and k_conv3x3_f16_w2<0, RES, OUTF, 7, false, false, 0> (7 x 2 wave tiles over 224 rows) for the f32-residual
+// and f32-output layers, plus the weight-image and conversion kernels: the only forms a product build instantiates, and the
+// product library reads NO environment variable here (tests/test_build_invariants.py holds both).  The template parameters
+// beyond those are measurement apparatus kept so that the tables in HISTORY.md 4b / 4h / 12 can be re-run on the same
+// source; they are instantiated and selectable only in a timing build (make EXTRA=-DAGZ_TIMING_EXPERIMENTS, see
+// launch_conv16_experiments): AGZ_C16_DM, AGZ_C16_Q / _QZ (bit-identical forms), AGZ_C16_POLICY, AGZ_C16_MEAS,
+// AGZ_C16_DEBUG / _RB / _PACE (results WRONG: parts of the loop compiled out), and -DAGZ_C16_WL=true (weights through a
+// wave-private LDS ring, round 4).
 #include "agz_nn.h"
 
 #include <hip/hip_fp16.h>
@@ -138,7 +136,9 @@ __device__ unsigned g_c16_pace = 0;
 // it would push the 1.2 MB of weights every tile re-reads out) / nt / sc0 sc1; bits 3 / 4 (measurement only, WRONG
 // results): drop the trickled result stores of every other workgroup / of all.  (A second switch on the residual loads
 // made the residual-carrying form spill 25 registers: this kernel has no register to give.)
+#ifdef AGZ_TIMING_EXPERIMENTS
 __device__ unsigned g_c16_policy = 0;
+#endif
 typedef unsigned c16_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void c16_store(c16_u4* gp, c16_u4 v, unsigned pol) {
   switch (pol & 3u) {
@@ -336,7 +336,11 @@ __global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _
   const int lx = l31 * 512 + 8 * hi + (((wave * 8) ^ l31) << 4);                              // lane's 8-byte group: lx ^ (piece << 4), piece 0..7 of the slice
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   u4 treg = {0, 0, 0, 0};
+#ifdef AGZ_TIMING_EXPERIMENTS
   const unsigned pol = __builtin_amdgcn_readfirstlane(g_c16_policy);
+#else
+  constexpr unsigned pol = 0;          // plain stores, nothing dropped: the product has no store-policy switch
+#endif
   // (measurement only, results WRONG: bit 3 = the result stores of every other workgroup are dropped, bit 4 = of all)
   const unsigned drop = 16u | ((blockIdx.x & 1u) ? 8u : 0u);
   char* yprev = nullptr;                                  // tile whose image is leaving: base of its rows in y
@@ -874,12 +878,17 @@ void launch_f32_to_f16(const float* x, uint16_t* y, const int* d_count, int bcap
 #ifndef AGZ_C16_WL
 #define AGZ_C16_WL false
 #endif
-void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale, const float* shift, const void* res,
-                       int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
-  const long rows = (long)bcap * N * N;
-  const _Float16* xh = (const _Float16*)x;
-  static int ncu = 0;
-  if (!ncu) AGZ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+#ifdef AGZ_TIMING_EXPERIMENTS
+// Timing-experiment dispatch of the fp16 tower layer (never in the product library).  Returns true when it launched.
+//   AGZ_C16_MEAS=32|96|224|480  measurement forms of the no-residual layer (tools/c16_meas.sh; results WRONG)
+//   AGZ_C16_POLICY              cache policy mask of the result stores (tools/c16_policy.sh)
+//   AGZ_C16_Q=0|1|2, AGZ_C16_QZ which form serves the half-in / half-out layers (bit-identical results)
+//   AGZ_C16_DM                  off-board fragments zeroed in registers
+//   AGZ_C16_DEBUG / _RB / _PACE round 2-4 variants: bit mask of what is compiled out (results WRONG)
+static bool launch_conv16_experiments(const _Float16* xh, const uint16_t* wi, const float* scale, const float* shift, const void* res,
+                                      int rk, void* y, int out_f32, const int* d_count, long rows, int ncu, int N, int relu,
+                                      hipStream_t s) {
+  const bool res_f32 = rk == 2;
   static const int meas = getenv("AGZ_C16_MEAS") ? atoi(getenv("AGZ_C16_MEAS")) : 0;
   static bool policy_set = false;
   if (!policy_set) {
@@ -887,36 +896,28 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
     const unsigned pm = getenv("AGZ_C16_POLICY") ? (unsigned)strtoul(getenv("AGZ_C16_POLICY"), nullptr, 0) : 0u;
     if (pm) AGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_c16_policy), &pm, sizeof(pm)));
   }
-  const int rk = !res ? 0 : (res_f32 ? 2 : 1);
-  if (meas && rk == 0 && !out_f32) {      // (measurement form of the no-residual layer: tools/c16_meas.sh)
+  if (meas && rk == 0 && !out_f32) {
     const int g7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
 #define AGZ_C16_MEAS_LAUNCH(MASK)                                                                                                    \
   hipLaunchKernelGGL((k_conv3x3_f16_w2<0, 0, false, W2_RB_PRODUCT, false, false, MASK>), dim3(g7), dim3(256), 0, s, xh, wi, scale, shift, res, \
                      y, d_count, N, relu)
     switch (meas) {
-      case 32: AGZ_C16_MEAS_LAUNCH(32); return;
-      case 96: AGZ_C16_MEAS_LAUNCH(96); return;
-      case 224: AGZ_C16_MEAS_LAUNCH(224); return;
-      case 480: AGZ_C16_MEAS_LAUNCH(480); return;
-      default: break;           // (any other value: the product form)
+      case 32: AGZ_C16_MEAS_LAUNCH(32); return true;
+      case 96: AGZ_C16_MEAS_LAUNCH(96); return true;
+      case 224: AGZ_C16_MEAS_LAUNCH(224); return true;
+      case 480: AGZ_C16_MEAS_LAUNCH(480); return true;
+      default: break;
     }
 #undef AGZ_C16_MEAS_LAUNCH
   }
-  // AGZ_C16_Q=1: half-in / half-out layers on the 2 x 2 form (k_conv3x3_f16_q); the f32-residual / f32-output layers stay here
-  // the half-in / half-out layers (38 of a tower's 40) run on the 2 x 2 form since round 5 (-1.8 % per configs[4] step in a
-  // same-box A/B, bit-identical results); AGZ_C16_Q=0: the 7 x 2 form for every layer, 2: the 2 x 2 form for the no-residual form only
   static const int quad = getenv("AGZ_C16_Q") ? atoi(getenv("AGZ_C16_Q")) : 1;
   if (quad && !res_f32 && !out_f32 && (quad == 1 || !res)) {
-    const int gq = std::min((int)((rows + QM - 1) / QM), ncu);
     static const bool qz = getenv("AGZ_C16_QZ") && atoi(getenv("AGZ_C16_QZ")) != 0;
-    if (qz) {
-      if (res) hipLaunchKernelGGL((k_conv3x3_f16_q<1, true>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)res, (_Float16*)y, d_count, N, relu);
-      else hipLaunchKernelGGL((k_conv3x3_f16_q<0, true>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)nullptr, (_Float16*)y, d_count, N, relu);
-      return;
-    }
-    if (res) hipLaunchKernelGGL((k_conv3x3_f16_q<1>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)res, (_Float16*)y, d_count, N, relu);
-    else hipLaunchKernelGGL((k_conv3x3_f16_q<0>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)nullptr, (_Float16*)y, d_count, N, relu);
-    return;
+    if (!qz) return false;                                  // the product's own 2 x 2 launch
+    const int gq = std::min((int)((rows + QM - 1) / QM), ncu);
+    if (res) hipLaunchKernelGGL((k_conv3x3_f16_q<1, true>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)res, (_Float16*)y, d_count, N, relu);
+    else hipLaunchKernelGGL((k_conv3x3_f16_q<0, true>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)nullptr, (_Float16*)y, d_count, N, relu);
+    return true;
   }
   const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
   static const bool zb = getenv("AGZ_C16_DM") && atoi(getenv("AGZ_C16_DM")) != 0;
@@ -941,9 +942,6 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
       else AGZ_C16_W2(D, 2, false, RB, G);             \
     }                                                  \
   } while (0)
-#ifdef AGZ_TIMING_EXPERIMENTS
-  // timing experiments only (make EXTRA=-DAGZ_TIMING_EXPERIMENTS, tools/c16_x.sh): AGZ_C16_DEBUG = bit mask of what is
-  // compiled out (wrong results), AGZ_C16_RB=4 = 128-row tiles, two workgroups per CU, direct epilogue
   static const int dbg = getenv("AGZ_C16_DEBUG") ? atoi(getenv("AGZ_C16_DEBUG")) : 0;
   static bool pace_set = false;
   if (!pace_set) {
@@ -954,31 +952,70 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   static const int rb = getenv("AGZ_C16_RB") ? atoi(getenv("AGZ_C16_RB")) : W2_RB_PRODUCT;
   if (rb == 4) {
     AGZ_C16_W2D(0, 4, std::min((int)((rows + 127) / 128), 2 * ncu));
-    return;
+    return true;
   }
   switch (dbg) {
-    case 1: AGZ_C16_W2D(1, W2_RB_PRODUCT, grid7); return;
-    case 3: AGZ_C16_W2D(3, W2_RB_PRODUCT, grid7); return;
-    case 5: AGZ_C16_W2D(5, W2_RB_PRODUCT, grid7); return;
-    case 9: AGZ_C16_W2D(9, W2_RB_PRODUCT, grid7); return;
-    case 15: AGZ_C16_W2D(15, W2_RB_PRODUCT, grid7); return;
-    case 32: AGZ_C16_W2D(32, W2_RB_PRODUCT, grid7); return;
-    case 16: AGZ_C16_W2D(16, W2_RB_PRODUCT, grid7); return;
-    case 48: AGZ_C16_W2D(48, W2_RB_PRODUCT, grid7); return;
-    case 64: AGZ_C16_W2D(64, W2_RB_PRODUCT, grid7); return;
-    case 128: AGZ_C16_W2D(128, W2_RB_PRODUCT, grid7); return;
-    case 256: AGZ_C16_W2D(256, W2_RB_PRODUCT, grid7); return;
-    case 512: AGZ_C16_W2D(512, W2_RB_PRODUCT, grid7); return;
-    case 1024: AGZ_C16_W2D(1024, W2_RB_PRODUCT, grid7); return;
-    case 1536: AGZ_C16_W2D(1536, W2_RB_PRODUCT, grid7); return;
-    case 544: AGZ_C16_W2D(544, W2_RB_PRODUCT, grid7); return;
-    case 34: AGZ_C16_W2D(34, W2_RB_PRODUCT, grid7); return;
-    case 2: AGZ_C16_W2D(2, W2_RB_PRODUCT, grid7); return;
+    case 1: AGZ_C16_W2D(1, W2_RB_PRODUCT, grid7); return true;
+    case 3: AGZ_C16_W2D(3, W2_RB_PRODUCT, grid7); return true;
+    case 5: AGZ_C16_W2D(5, W2_RB_PRODUCT, grid7); return true;
+    case 9: AGZ_C16_W2D(9, W2_RB_PRODUCT, grid7); return true;
+    case 15: AGZ_C16_W2D(15, W2_RB_PRODUCT, grid7); return true;
+    case 32: AGZ_C16_W2D(32, W2_RB_PRODUCT, grid7); return true;
+    case 16: AGZ_C16_W2D(16, W2_RB_PRODUCT, grid7); return true;
+    case 48: AGZ_C16_W2D(48, W2_RB_PRODUCT, grid7); return true;
+    case 64: AGZ_C16_W2D(64, W2_RB_PRODUCT, grid7); return true;
+    case 128: AGZ_C16_W2D(128, W2_RB_PRODUCT, grid7); return true;
+    case 256: AGZ_C16_W2D(256, W2_RB_PRODUCT, grid7); return true;
+    case 512: AGZ_C16_W2D(512, W2_RB_PRODUCT, grid7); return true;
+    case 1024: AGZ_C16_W2D(1024, W2_RB_PRODUCT, grid7); return true;
+    case 1536: AGZ_C16_W2D(1536, W2_RB_PRODUCT, grid7); return true;
+    case 544: AGZ_C16_W2D(544, W2_RB_PRODUCT, grid7); return true;
+    case 34: AGZ_C16_W2D(34, W2_RB_PRODUCT, grid7); return true;
+    case 2: AGZ_C16_W2D(2, W2_RB_PRODUCT, grid7); return true;
     default: break;
   }
-#endif
-  AGZ_C16_W2D(0, W2_RB_PRODUCT, grid7);
+  if (zb || !quad || (quad == 2 && res)) {                  // a non-product form of a product layer
+    AGZ_C16_W2D(0, W2_RB_PRODUCT, grid7);
+    return true;
+  }
 #undef AGZ_C16_W2D
+#undef AGZ_C16_W2
+  return false;
+}
+#endif
+
+void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale, const float* shift, const void* res,
+                       int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
+  const long rows = (long)bcap * N * N;
+  const _Float16* xh = (const _Float16*)x;
+  static int ncu = 0;
+  if (!ncu) AGZ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+  const int rk = !res ? 0 : (res_f32 ? 2 : 1);
+#ifdef AGZ_TIMING_EXPERIMENTS
+  // Everything an environment variable can select lives in this block: timing builds only (make EXTRA=-DAGZ_TIMING_EXPERIMENTS).
+  // The product library reads no AGZ_C16_* variable and holds none of these instantiations (tests/test_build_invariants.py).
+  if (launch_conv16_experiments(xh, wi, scale, shift, res, rk, y, out_f32, d_count, rows, ncu, N, relu, s)) return;
+#endif
+  // the half-in / half-out layers (38 of a tower's 40): 2 x 2 waves over a 256-row x 256-cout tile (round 5: -1.8 % per
+  // configs[4] step against the 7 x 2 form in a same-box A/B, bit-identical results)
+  if (!res_f32 && !out_f32) {
+    const int gq = std::min((int)((rows + QM - 1) / QM), ncu);
+    if (res) hipLaunchKernelGGL((k_conv3x3_f16_q<1>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)res, (_Float16*)y, d_count, N, relu);
+    else hipLaunchKernelGGL((k_conv3x3_f16_q<0>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)nullptr, (_Float16*)y, d_count, N, relu);
+    return;
+  }
+  // the f32-residual and f32-output layers (first and last of a tower): 7 x 2 wave tiles over 224 rows, direct epilogue
+  const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
+#define AGZ_C16_W2(R, OF)                                                                                                          \
+  hipLaunchKernelGGL((k_conv3x3_f16_w2<0, R, OF, W2_RB_PRODUCT, AGZ_C16_WL, false>), dim3(grid7), dim3(256), 0, s, xh, wi, scale, \
+                     shift, res, y, d_count, N, relu)
+  if (out_f32) {
+    if (rk == 0) AGZ_C16_W2(0, true);
+    else if (rk == 1) AGZ_C16_W2(1, true);
+    else AGZ_C16_W2(2, true);
+  } else {
+    AGZ_C16_W2(2, false);           // (rk == 2: the half-output layer behind an f32 residual)
+  }
 #undef AGZ_C16_W2
 }
 

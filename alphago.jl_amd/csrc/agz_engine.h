@@ -101,6 +101,8 @@ class Engine {
   int tree_op(TreeArgs& T, int32_t* r0);           // returns the op's agz_status
   int tree_search_select(int g, int par, int* nleaves);
   void tree_leaf_features(int g, float* feats_out);
+  void tree_leaf_positions(int g, int32_t* nodes, int8_t* boards, int8_t* deltas, int32_t* ndeltas, int8_t* to_play,
+                           agz_position_info* info);
   int tree_search_incorporate(int g, const float* pi, const float* v);   // pi == NULL: engine's own network
   void game_state(int g, GameState* out);
   void game_patch(int g, const GameState& s);
@@ -135,7 +137,8 @@ class Engine {
   DevBuf<float> d_x32_, d_pi_, d_v_, d_whcn_;
   DevBuf<int32_t> d_count_;
   // staging for ABI calls
-  DevBuf<int8_t> s_boards_, s_deltas_, s_tp_, s_boards_out_, s_legal_;
+  DevBuf<int8_t> s_boards_, s_deltas_, s_tp_, s_boards_out_, s_legal_, s_leafb_;
+  DevBuf<uint8_t> s_leafrows_;
   DevBuf<int32_t> s_i32a_, s_i32b_, s_i32c_, s_i32d_;
   DevBuf<float> s_f32a_, s_f32b_;
   DevBuf<int16_t> s_i16a_;
@@ -144,6 +147,7 @@ class Engine {
   DevBuf<int32_t> s_iout_;
   int external_batch_ = 0;
   int tree_batch_ = 0;
+  int64_t abandoned_ = 0;       // games dropped by slot_abandon since the last selfplay_start
   // replay arena
   DevBuf<uint8_t> rp_buf_, s_pack_;
   size_t rp_used_ = 0;

@@ -194,6 +194,34 @@ __global__ __launch_bounds__(kWave) void k_leaf_features(View V, int g0, float* 
   leaf_features(w, V, g, k, x32 ? x32 + row * V.P * 32 : nullptr, whcn ? whcn + row * 17 * V.P : nullptr);
 }
 
+// The Vector{Position} a caller-supplied network receives (mcts_play.jl:89): per collected leaf of slot g, its own
+// board and the up-to-7 older boards behind the history planes (the same sources k_leaf_features reads), its NodeMeta
+// and the move before its last one -- gathered into contiguous rows for ONE copy to the host.
+struct LeafPosRow {
+  NodeMeta m;
+  int32_t node, plen, prev_move, pad;
+};
+__global__ __launch_bounds__(kWave) void k_leaf_positions(View V, int g, int8_t* boards8, LeafPosRow* rows) {
+  const int k = blockIdx.x;
+  if (k >= V.gs[g].nleaves) return;
+  const long li = (long)g * V.par + k;
+  const int P = V.P;
+  for (int s = 0; s < 8; ++s) {
+    const int src = V.leaf_featsrc[li * 8 + s];
+    const int8_t* b = src >= 0 ? V.board + node_index(V, g, src) * V.PP : V.hist + ((long)g * 7 + (-src - 1)) * V.PP;
+    for (int p = threadIdx.x; p < P; p += kWave) boards8[((long)k * 8 + s) * P + p] = b[p];
+  }
+  if (threadIdx.x == 0) {
+    LeafPosRow r;
+    r.node = V.leaf_node[li];
+    r.plen = V.leaf_plen[li];
+    r.m = V.meta[node_index(V, g, r.node)];
+    r.prev_move = r.m.parent >= 0 ? V.meta[node_index(V, g, r.m.parent)].last_move : -1;
+    r.pad = 0;
+    rows[k] = r;
+  }
+}
+
 __global__ __launch_bounds__(kWave) void k_tree_op(View V, TreeArgs T) {
   AGZ_SCRATCH(S)
   HipWave w;
@@ -480,6 +508,7 @@ void Engine::net_select(int which) {
 void Engine::start(int64_t total_games) {
   V_.total_games = total_games;
   rec_sent_ = 0;
+  abandoned_ = 0;
   stepped_ = false;
   AGZ_HIP(hipMemsetAsync(V_.counters, 0, sizeof(unsigned long long) * CT_COUNT, stream_));
   AGZ_HIP(hipMemsetAsync(V_.ar_hdr, 0, sizeof(int32_t) * 5 * (V_.games / 2 + 1), stream_));
@@ -616,11 +645,12 @@ void Engine::stats(agz_stats* out) {
   out->pool_short_searches = (int64_t)c[CT_POOL_SHORT];
   out->peak_nodes_per_game = (int64_t)c[CT_PEAK_NODES];
   out->node_capacity = V_.cap;
+  out->abandoned_games = abandoned_;
   for (const auto& g : gs) {
     out->nodes_in_use += g.nodes_used;
     out->peak_nodes_per_game = std::max<int64_t>(out->peak_nodes_per_game, g.nodes_used);
     out->live_games += (g.phase != G_RETIRED && g.phase != G_IDLE);
-    out->stalled_games += (g.err == AGZ_POOL_EXHAUSTED && g.phase == G_SEARCH);
+    out->stalled_games += (g.stalled != 0 && g.phase == G_SEARCH);
   }
 }
 
@@ -632,7 +662,7 @@ void Engine::slot_status(int32_t* status, int32_t* nodes, int32_t* moves) {
   AGZ_HIP(hipMemcpyAsync(gs.data(), V_.gs, sizeof(GameState) * gs.size(), hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
   for (int g = 0; g < V_.games; ++g) {
-    if (status) status[g] = gs[g].err;
+    if (status) status[g] = (gs[g].stalled && gs[g].phase == G_SEARCH) ? AGZ_POOL_EXHAUSTED : (gs[g].err == AGZ_POOL_EXHAUSTED ? AGZ_OK : gs[g].err);
     if (nodes) nodes[g] = gs[g].nodes_used;
     if (moves) moves[g] = gs[g].move_count;
   }
@@ -652,8 +682,10 @@ void Engine::slot_abandon(int g) {
   G.nleaves = 0;
   G.npend = 0;
   G.err = 0;
+  G.stalled = 0;
   AGZ_HIP(hipMemcpyAsync(V_.gs + g, &G, sizeof(G), hipMemcpyHostToDevice, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
+  ++abandoned_;
 }
 
 // ---- records
@@ -1310,6 +1342,47 @@ void Engine::tree_leaf_features(int g, float* feats_out) {
   AGZ_HIP(hipMemcpyAsync(feats_out, d_whcn_.p, sizeof(float) * (size_t)tree_batch_ * 17 * V_.P,
                          hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
+}
+
+// agz_tree_leaf_positions: the leaves of the last tree_search_select as the reference's GoPosition fields
+// (board.jl:271-306): board, board_deltas newest first (delta_k = B_k - B_{k+1}: +colour at the played point and where
+// an opponent stone vanished, board.jl:479-481,505-506), to_play, n, ko, caps, the last two moves
+void Engine::tree_leaf_positions(int g, int32_t* nodes, int8_t* boards, int8_t* deltas, int32_t* ndeltas,
+                                 int8_t* to_play, agz_position_info* info) {
+  check_game(g);
+  const int n = tree_batch_;
+  if (n <= 0) return;
+  const int P = V_.P;
+  s_leafb_.ensure((size_t)V_.par * 8 * P);
+  s_leafrows_.ensure((size_t)V_.par * sizeof(LeafPosRow));
+  hipLaunchKernelGGL(k_leaf_positions, dim3(n), dim3(kWave), 0, stream_, V_, g, s_leafb_.p, (LeafPosRow*)s_leafrows_.p);
+  std::vector<int8_t> b8((size_t)n * 8 * P);
+  std::vector<LeafPosRow> rows(n);
+  GameState gs;
+  AGZ_HIP(hipMemcpyAsync(b8.data(), s_leafb_.p, b8.size(), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(rows.data(), s_leafrows_.p, sizeof(LeafPosRow) * n, hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipMemcpyAsync(&gs, V_.gs + g, sizeof(GameState), hipMemcpyDeviceToHost, stream_));
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  for (int k = 0; k < n; ++k) {
+    const LeafPosRow& r = rows[k];
+    const int avail = std::min(7, (r.plen - 1) + gs.hist_len);   // older boards that exist (record_leaf)
+    const int8_t* b = b8.data() + (size_t)k * 8 * P;
+    if (nodes) nodes[k] = r.node;
+    if (boards) std::memcpy(boards + (size_t)k * P, b, P);
+    if (deltas) {
+      int8_t* d = deltas + (size_t)k * 7 * P;
+      std::memset(d, 0, (size_t)7 * P);
+      for (int s = 0; s < avail; ++s)
+        for (int p = 0; p < P; ++p) d[(size_t)s * P + p] = (int8_t)(b[(size_t)s * P + p] - b[(size_t)(s + 1) * P + p]);
+    }
+    if (ndeltas) ndeltas[k] = avail;
+    if (to_play) to_play[k] = r.m.to_play;
+    if (info) {
+      agz_position_info& o = info[k];
+      o.n = r.m.n; o.to_play = r.m.to_play; o.ko = r.m.ko; o.caps_black = r.m.caps_b; o.caps_white = r.m.caps_w;
+      o.last_move = r.m.last_move; o.prev_move = r.prev_move; o.history_len = avail; o.komi = gs.komi;
+    }
+  }
 }
 
 int Engine::tree_search_incorporate(int g, const float* pi, const float* v) {

@@ -465,6 +465,9 @@ void Net::set(int layer, int kind, const float* data, int64_t count) {
   }
   for (const auto& sl : slots_)
     if (sl.layer == layer && sl.kind == kind) upload_slot(sl);
+  // the copy reads a pageable host vector: drain it before anything (init_synthetic, conv_init, ~Net) may reassign or
+  // free that vector.  ~20 us per parameter; bulk device-side paths (train step, broadcast) do not come here.
+  AGZ_HIP(hipStreamSynchronize(stream_));
   derived_dirty_ = true;
 }
 
@@ -800,8 +803,12 @@ void launch_conv3x3_direct_taps(const float* x, const float* wt, const float* on
 // overlap, so the profile keeps ONE event pair around the whole tower (2 * tower layers).  Returns whether this tower is
 // being timed.
 static int tower_chunks() {
-  static const int n = getenv("AGZ_TOWER_CHUNKS") ? atoi(getenv("AGZ_TOWER_CHUNKS")) : 0;
+#ifdef AGZ_TIMING_EXPERIMENTS
+  static const int n = getenv("AGZ_TOWER_CHUNKS") ? atoi(getenv("AGZ_TOWER_CHUNKS")) : 0;     // tools/chunks_sweep.sh
   return n;
+#else
+  return 0;
+#endif
 }
 
 bool Net::fork_chains(int parts) {

@@ -1266,7 +1266,16 @@ AGZ_FN void game_pre(W& w, const View& V, Scratch& S, int g) {
     return;
   }
   bool agz_moved = false;
-  if (G.phase == G_SEARCH && (!(G.rootN < G.target) || pool_full_can_move(w, V, g))) { game_move_phase(w, V, S, g); agz_moved = true; }
+  if (G.phase == G_SEARCH) {
+    const bool full = G.err == AGZ_POOL_EXHAUSTED;
+    const bool can_move = !(G.rootN < G.target) || pool_full_can_move(w, V, g);
+    if (w.leader()) G.stalled = full && !can_move;      // what agz_stats.stalled_games / agz_slot_status report
+    w.sync();
+    if (can_move) { game_move_phase(w, V, S, g); agz_moved = true; }
+  } else if (G.stalled) {
+    if (w.leader()) G.stalled = 0;
+    w.sync();
+  }
   (void)agz_moved;
   AGZ_STAMP_BEGIN_AGAIN(w);
   if (G.phase == G_IDLE) {

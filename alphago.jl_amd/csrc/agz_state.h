@@ -63,7 +63,11 @@ struct GameState {
   int32_t garbage;           // nodes on the deferred-free stack (tail of the slot's free list)
   int32_t npend;             // leaves created by this step's select phase whose board update waits for k_expand
   int32_t short_searches;    // moves of this game played before their budget was spent (full pool, AGZ_POOL_MOVE_EARLY)
+  int32_t stalled;           // set by game_pre: the pool is full AND this game could not move early -- it is waiting
+                             // (G.err alone also reads EXHAUSTED between a refused allocation and the early move of
+                             // the next step: ADVICE r5)
 };
+static_assert(sizeof(GameState) == 112, "GameState layout (tests/hs.py mirrors it)");
 
 constexpr int kMaxPend = 16;    // deferred leaf expansions per game and step (2 x parallel_readouts at most)
 

@@ -1147,7 +1147,11 @@ void launch_wino_tower(const void* d_layers, int layers, int* d_sched, const int
               "batch of %d positions at %dx%d: tile index / activation byte offset exceeds 32 bits", bcap, N, N);
   const int blocks_cap = (int)wino_blocks(bcap, T);
   (void)hipMemsetAsync(d_sched, 0, sizeof(int) * wino_tower_sched_ints(layers, bcap, N), s);
+#ifdef AGZ_TIMING_EXPERIMENTS
   static const int order = getenv("AGZ_TOWER_ORDER") ? atoi(getenv("AGZ_TOWER_ORDER")) : 0;
+#else
+  constexpr int order = 0;
+#endif
   if (split)
     hipLaunchKernelGGL((k_wino_tower<true>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T, order);
   else

@@ -17,9 +17,13 @@ features N x N x 17 x B and pi A x B -- so arrays cross without copies or permut
 =#
 module AlphaGoMI
 
+using Printf: @sprintf
+using Random
+
 export GoEnv, Position, NeuralNet, MCTSPlayer, selfplay, extract_data, initialize_game!,
        tree_search!, pick_move, play_move!, should_resign, is_done, set_result!, all_legal_moves,
-       score, result, IllegalMove, to_flat, from_flat,
+       score, result, result_string, IllegalMove, to_flat, from_flat, PlayerMove, BLACK, WHITE,
+       SelfPlayPlayer, get_replay_batch, Momentum, _train, seed!,
        # the node-level surface test/test_mcts.jl:2-5 and test/test_mcts_player.jl:3-6 import
        MCTSNode, select_leaf, maybe_add_child!, add_virtual_loss!, revert_virtual_loss!,
        incorporate_results!, inject_noise!, child_action_score, child_Q, child_U, child_N, child_W,
@@ -64,11 +68,12 @@ struct AgzGameHeader
   final_score::Float32; short_searches::Int32
 end
 
-struct AgzStats            # agz_stats, include/agz.h: seventeen Int64 counters
+struct AgzStats            # agz_stats, include/agz.h: eighteen Int64 counters
   steps::Int64; positions::Int64; games_started::Int64; games_finished::Int64; evals::Int64
   duplicate_evals::Int64; terminal_visits::Int64; root_visits::Int64; nodes_in_use::Int64
   pool_exhausted::Int64; resigned_games::Int64; live_games::Int64; records_dropped::Int64
   pool_short_searches::Int64; peak_nodes_per_game::Int64; stalled_games::Int64; node_capacity::Int64
+  abandoned_games::Int64
 end
 
 mutable struct Engine
@@ -188,6 +193,8 @@ function score(pos::Position)
   out[1]
 end
 result(pos::Position) = (s = score(pos); s > 0 ? 1 : s < 0 ? -1 : 0)          # board.jl:535-544
+result_string(s::Real) = s > 0 ? "B+" * @sprintf("%.1f", s) : s < 0 ? "W+" * @sprintf("%.1f", -s) : "DRAW"
+result_string(pos::Position) = result_string(score(pos))                      # board.jl:546-555
 
 # play_move!(pos, c; mutate = false), board.jl:451-509 / pass_move! :426-440
 function play_move!(pos::Position, c; mutate = false)
@@ -274,6 +281,8 @@ mutable struct MCTSPlayer
   result_string::String
   resign_threshold::Float64
   engine::Engine
+  start::Union{Nothing, Position}       # the position initialize_game! was given
+  recent::Vector{PlayerMove}            # start.recent + every move played since: root.position.recent (board.jl:299)
 end
 function MCTSPlayer(env::GoEnv, network; num_readouts = 800, two_player_mode = false,
                     resign_threshold = -0.9, seed = 0)
@@ -283,7 +292,7 @@ function MCTSPlayer(env::GoEnv, network; num_readouts = 800, two_player_mode = f
              parallel_readouts = 64, two_player_mode = two_player_mode,
              resign_threshold = resign_threshold, seed = seed, external_network = !(network isa NeuralNet))
   MCTSPlayer(env, network, num_readouts, two_player_mode, τ, Float32[], Vector{Float32}[], 0, "",
-             resign_threshold, e)
+             resign_threshold, e, nothing, PlayerMove[])
 end
 
 function initialize_game!(p::MCTSPlayer, pos = nothing)                        # mcts_play.jl:110-118
@@ -304,6 +313,7 @@ function initialize_game!(p::MCTSPlayer, pos = nothing)                        #
         (Ptr{Cvoid}, Int32, Ptr{Int8}, Ref{AgzPositionInfo}, Ptr{Int8}),
         p.engine.handle, 0, pos.board, info, k == 0 ? C_NULL : hist))      # ccall roots `hist` for the call
   p.result = 0; p.qs = Float32[]; p.searches_π = Vector{Float32}[]
+  p.start = pos; p.recent = copy(pos.recent)
   p
 end
 
@@ -329,25 +339,64 @@ function child_N(p::MCTSPlayer)
   out
 end
 
-# tree_search!(player, parallel_readouts = 8), mcts_play.jl:73-98; returns the number of leaves
+# The leaves the last agz_tree_search_select collected, as the reference's GoPosition fields (agz_tree_leaf_positions):
+# node handles and, unless `nodes_only`, one Position per leaf -- board, board_deltas (newest first), to_play, n, ko,
+# caps, the last two moves.
+function leaf_positions(p::MCTSPlayer, B::Int; nodes_only::Bool = false)
+  env = p.env; N = env.N
+  nodes = zeros(Int32, B)
+  if nodes_only
+    check(p.engine, ccall((:agz_tree_leaf_positions, libagz), Int32,
+          (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Ptr{Int8}, Ptr{AgzPositionInfo}),
+          p.engine.handle, 0, nodes, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+    return nodes, Position[]
+  end
+  boards = zeros(Int8, N, N, B); deltas = zeros(Int8, N, N, 7, B); nd = zeros(Int32, B); tp = zeros(Int8, B)
+  info = Vector{AgzPositionInfo}(undef, B)
+  check(p.engine, ccall((:agz_tree_leaf_positions, libagz), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Ptr{Int8}, Ptr{AgzPositionInfo}),
+        p.engine.handle, 0, nodes, boards, deltas, nd, tp, info))
+  to_pm(a, color) = PlayerMove(color, a == N^2 ? nothing : from_flat(a + 1, env))
+  positions = Position[]
+  for b in 1:B
+    i = info[b]
+    recent = PlayerMove[]
+    i.prev_move >= 0 && push!(recent, to_pm(Int(i.prev_move), Int(i.to_play)))
+    i.last_move >= 0 && push!(recent, to_pm(Int(i.last_move), -Int(i.to_play)))
+    push!(positions, Position(env, boards[:, :, b], Int(i.n), i.komi, (Int(i.caps_black), Int(i.caps_white)),
+                              i.ko < 0 ? nothing : from_flat(i.ko + 1, env), recent,
+                              deltas[:, :, 1:nd[b], b], Int(i.to_play), false))
+  end
+  nodes, positions
+end
+
+# Tracker-era networks answer with TrackedArrays (the reference's DummyNet returns `param(...)`,
+# test/test_mcts_player.jl:22-32); mcts_play.jl:90 unwraps them with `.data`
+untrack(x) = hasproperty(x, :data) ? getproperty(x, :data) : x
+
+# tree_search!(player, parallel_readouts = 8), mcts_play.jl:73-98; returns the leaves (Vector{MCTSNode}) like the
+# reference.  A caller-supplied network receives `positions::Vector{Position}` with length(positions) == number of
+# leaves -- the reference's `mcts_player.network([leaf.position for leaf in leaves])` (mcts_play.jl:89).
 function tree_search!(p::MCTSPlayer, parallel_readouts = 8)
   n = Ref{Int32}(0)
-  if p.network isa NeuralNet
-    check(p.engine, ccall((:agz_tree_search, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}),
-                          p.engine.handle, 0, parallel_readouts, n))
-    return Int(n[])
-  end
   check(p.engine, ccall((:agz_tree_search_select, libagz), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}),
                         p.engine.handle, 0, parallel_readouts, n))
-  B = Int(n[]); B == 0 && return 0
-  feats = zeros(Float32, p.env.N, p.env.N, 17, B)
-  check(p.engine, ccall((:agz_tree_leaf_features, libagz), Int32, (Ptr{Cvoid}, Int32, Ptr{Float32}),
-                        p.engine.handle, 0, feats))
-  π, v = p.network(feats)                       # A x B and B values, Float32
+  B = Int(n[])
+  if p.network isa NeuralNet || B == 0              # the engine's own network evaluates the leaves on the device
+    nodes, _ = B == 0 ? (Int32[], Position[]) : leaf_positions(p, B; nodes_only = true)
+    check(p.engine, ccall((:agz_tree_search_incorporate, libagz), Int32,
+                          (Ptr{Cvoid}, Int32, Ptr{Float32}, Ptr{Float32}), p.engine.handle, 0, C_NULL, C_NULL))
+    return [MCTSNode(p, id) for id in nodes]
+  end
+  nodes, positions = leaf_positions(p, B)
+  move_probs, values = p.network(positions)                                     # mcts_play.jl:89
+  move_probs, values = untrack(move_probs), untrack(values)                     # :90
+  size(move_probs) == (p.env.action_space, B) && length(values) == B ||
+    throw(AssertionError("network returned $(size(move_probs)) / $(length(values)) values for $B positions"))
   check(p.engine, ccall((:agz_tree_search_incorporate, libagz), Int32,
                         (Ptr{Cvoid}, Int32, Ptr{Float32}, Ptr{Float32}),
-                        p.engine.handle, 0, Float32.(π), Float32.(vec(v))))
-  B
+                        p.engine.handle, 0, Matrix{Float32}(move_probs), Vector{Float32}(vec(values))))
+  [MCTSNode(p, id) for id in nodes]
 end
 
 function pick_move(p::MCTSPlayer)                                               # mcts_play.jl:52-71
@@ -376,6 +425,7 @@ function play_move!(p::MCTSPlayer, c)                                           
     pop!(p.qs)
     return false
   end
+  push!(p.recent, PlayerMove(Int(info.pos.to_play), c))
   true
 end
 
@@ -387,7 +437,8 @@ struct MCTSNode
   player::MCTSPlayer
   id::Int32
 end
-Base.getproperty(p::MCTSPlayer, s::Symbol) = s === :root ? MCTSNode(p, root(p)) : getfield(p, s)
+Base.getproperty(p::MCTSPlayer, s::Symbol) =
+  s === :root ? MCTSNode(p, root(p)) : s === :position ? position(MCTSNode(p, root(p))) : getfield(p, s)
 Base.:(==)(a::MCTSNode, b::MCTSNode) = getfield(a, :player) === getfield(b, :player) && getfield(a, :id) == getfield(b, :id)
 # The reference's tests read a node's state as FIELDS (test/test_mcts.jl:52-70, test/test_mcts_player.jl:150-175:
 # node.position, .children, .child_N, .child_prior, .fmove, .parent, .is_expanded ...; src/mcts.jl:41-53): each is one
@@ -506,8 +557,12 @@ function position(x::MCTSNode)                                                  
   # pass rule and the double-pass end need, mcts.jl:119-126); the full move list of a game is extract_data's
   # (agz_records_game).  `board_deltas` is not rebuilt here: features come from agz_features / the leaf feature call.
   to_pm(a, color) = PlayerMove(color, a == env.N^2 ? nothing : from_flat(a + 1, env))
-  if info.pos.prev_move >= 0 push!(pos.recent, to_pm(Int(info.pos.prev_move), pos.to_play)) end
-  if info.pos.last_move >= 0 push!(pos.recent, to_pm(Int(info.pos.last_move), -pos.to_play)) end
+  if x.id == root(p)
+    pos.recent = copy(getfield(p, :recent))       # the player's root: the game's whole move list (extract_data replays it)
+  else
+    if info.pos.prev_move >= 0 push!(pos.recent, to_pm(Int(info.pos.prev_move), pos.to_play)) end
+    if info.pos.last_move >= 0 push!(pos.recent, to_pm(Int(info.pos.last_move), -pos.to_play)) end
+  end
   pos
 end
 
@@ -537,61 +592,158 @@ end
 
 function set_result!(p::MCTSPlayer, winner, was_resign)                         # mcts_play.jl:100-108
   p.result = winner
-  p.result_string = was_resign ? (winner == BLACK ? "B+R" : "W+R") : "see final position"
+  p.result_string = was_resign ? (winner == BLACK ? "B+R" : "W+R") : result_string(position(p.root))
 end
 
-# ------------------------------------------------------------------ batched self-play
-# selfplay(env, nn, num_ro) -> one finished game (src/selfplay.jl:1-45); with `games = G` the same
-# loop runs for G concurrent games on the device and a vector of GameRecord comes back.
-struct GameRecord
-  game_id::UInt64
-  moves::Vector{Int}                    # 1-based flat moves, N^2+1 = pass
-  searches_π::Vector{Vector{Float32}}
+# replay_position(pos, result), board.jl:557-578: the positions before each move of `recent`, from the empty board
+function replay_positions(env::GoEnv, komi, recent::Vector{PlayerMove})
+  positions = Position[]
+  pos = Position(env; komi = komi)
+  for pm in recent
+    push!(positions, pos)
+    pos = play_move!(pos, pm.move)
+  end
+  positions, pos
+end
+
+# extract_data(player) -> (positions, pis, results), mcts_play.jl:126-139 -- ONE argument, as train.jl:58 calls it
+function extract_data(p::MCTSPlayer)
+  rootpos = position(p.root)
+  length(p.searches_π) == rootpos.n || throw(AssertionError("length(searches_π) == root.position.n"))      # :127
+  rootpos.n == length(rootpos.recent) || throw(AssertionError("GoPosition history is incomplete"))          # board.jl:568
+  positions, _ = replay_positions(p.env, rootpos.komi, rootpos.recent)
+  positions, deepcopy(p.searches_π), fill(p.result, length(positions))
+end
+
+# ------------------------------------------------------------------ self-play
+# selfplay(env, nn, num_ro) -> the finished game's player (src/selfplay.jl:1-45,:44), exactly the call train() makes
+# (train.jl:57).  With `games = G` (ours) the same loop runs for G concurrent games on the device and a Vector of the
+# same objects comes back, ordered by game id.
+#
+# SelfPlayPlayer is the MCTSPlayer of ONE finished game, read-only: the fields train() and extract_data read
+# (mcts_play.jl:3-15) -- result, result_string, qs, searches_π, root.position (the final GoPosition with its whole
+# `recent`: .n, .board, .caps ...) -- as the device recorded them.  The tree stayed on the device and its slot was
+# recycled.  It also carries the record's own fields (game_id, moves as 1-based flat moves, short_searches).
+struct FinishedRoot
+  position::Position
+end
+struct SelfPlayPlayer
+  env::GoEnv
+  network
+  num_readouts::Int
+  two_player_mode::Bool
+  τ_threshold::Int
   qs::Vector{Float32}
+  searches_π::Vector{Vector{Float32}}
   result::Int
   result_string::String
-  short_searches::Int                    # moves played on fewer than num_ro readouts (full node pool, agz_config.pool_policy); 0 = the reference's game
+  root::FinishedRoot
+  resign_threshold::Float64
+  position::Position
+  positions::Vector{Position}           # the position before each move (replay_position, board.jl:557-578)
+  game_id::UInt64
+  moves::Vector{Int}                    # 1-based flat moves, N^2+1 = pass
+  short_searches::Int                   # moves played on fewer than num_ro readouts (full node pool, agz_config.pool_policy); 0 = the reference's game
+end
+is_done(p::SelfPlayPlayer) = true
+get_position(p::SelfPlayPlayer) = p.root.position
+
+# extract_data(player), mcts_play.jl:126-139: every result entry is the final game result
+function extract_data(p::SelfPlayPlayer)
+  length(p.searches_π) == p.root.position.n || throw(AssertionError("length(searches_π) == root.position.n"))
+  copy(p.positions), deepcopy(p.searches_π), fill(p.result, length(p.positions))
 end
 
-function selfplay(env::GoEnv, nn::NeuralNet, num_ro::Int = 800; games::Int = 1, slots::Int = min(games, 1024),
-                  seed = 0)
-  e = Engine(board_size = env.N, tower_height = nn.tower_height, games = slots, num_readouts = num_ro,
-             seed = seed, record_capacity_games = games + 8)
+# The reference draws from Julia's global RNG (selfplay.jl:9, mcts.jl:133,235, mcts_play.jl:61,66), so successive
+# selfplay calls see successive random numbers.  The engine's draws are a function of (seed, game id, move, site)
+# (include/agz_draws.h): seed!(s) is Random.seed!(s) for it, and every selfplay call plays the next unused game ids.
+const STREAM = Ref((UInt64(0), UInt64(0)))                     # (seed, next game id)
+seed!(s::Integer) = (STREAM[] = (UInt64(s), UInt64(0)); nothing)
+
+function selfplay(env::GoEnv, nn::NeuralNet, num_ro::Int = 800; games::Union{Nothing, Int} = nothing,
+                  slots::Union{Nothing, Int} = nothing, seed = nothing, game_id_base = nothing)
+  G = games === nothing ? 1 : games
+  if seed === nothing
+    seed, next = STREAM[]
+    if game_id_base === nothing
+      game_id_base = next
+      STREAM[] = (seed, next + UInt64(G))
+    end
+  end
+  game_id_base === nothing && (game_id_base = 0)
+  e = Engine(board_size = env.N, tower_height = nn.tower_height, games = slots === nothing ? min(G, 1024) : slots,
+             num_readouts = num_ro, seed = seed, game_id_base = game_id_base, record_capacity_games = G + 8)
   copy_weights!(e, nn.engine)
-  check(e, ccall((:agz_selfplay_start, libagz), Int32, (Ptr{Cvoid}, Int64), e.handle, games))
-  while ccall((:agz_records_count, libagz), Int64, (Ptr{Cvoid},), e.handle) < games
+  check(e, ccall((:agz_selfplay_start, libagz), Int32, (Ptr{Cvoid}, Int64), e.handle, G))
+  while ccall((:agz_records_count, libagz), Int64, (Ptr{Cvoid},), e.handle) < G
     check(e, ccall((:agz_selfplay_step, libagz), Int32, (Ptr{Cvoid}, Int32), e.handle, 16))
     check_pool(e)     # a game whose node pool ran out cannot finish: raise instead of stepping for ever
   end
-  recs = GameRecord[]
+  players = SelfPlayPlayer[]
   A = env.action_space
-  for k in 0:games-1
+  τ = (env.N * env.N ÷ 12) ÷ 2 * 2
+  for k in 0:G-1
     h = Ref{AgzGameHeader}()
     check(e, ccall((:agz_records_header, libagz), Int32, (Ptr{Cvoid}, Int64, Ref{AgzGameHeader}), e.handle, k, h))
     n = Int(h[].num_moves)
     moves = zeros(Int16, max(n, 1)); pis = zeros(Float32, A, max(n, 1)); qs = zeros(Float32, max(n, 1))
     check(e, ccall((:agz_records_game, libagz), Int32, (Ptr{Cvoid}, Int64, Ptr{Int16}, Ptr{Float32}, Ptr{Float32}),
                    e.handle, k, moves, pis, qs))
-    rs = h[].was_resign != 0 ? (h[].result == BLACK ? "B+R" : "W+R") :
-         h[].final_score > 0 ? "B+$(round(h[].final_score, digits = 1))" :
-         h[].final_score < 0 ? "W+$(round(-h[].final_score, digits = 1))" : "DRAW"
-    push!(recs, GameRecord(h[].game_id, Int.(moves[1:n]) .+ 1, [pis[:, i] for i in 1:n], qs[1:n],
-                           Int(h[].result), rs, Int(h[].short_searches)))
+    rs = h[].was_resign != 0 ? (h[].result == BLACK ? "B+R" : "W+R") : result_string(h[].final_score)
+    fmoves = Int.(moves[1:n]) .+ 1
+    recent, color = PlayerMove[], BLACK
+    for f in fmoves
+      push!(recent, PlayerMove(color, from_flat(f, env))); color = -color
+    end
+    positions, final = replay_positions(env, 7.5, recent)
+    push!(players, SelfPlayPlayer(env, nn, num_ro, false, τ, qs[1:n], [pis[:, i] for i in 1:n], Int(h[].result), rs,
+                                  FinishedRoot(final), h[].resign_disabled != 0 ? -1.0 : -0.9, final, positions,
+                                  h[].game_id, fmoves, Int(h[].short_searches)))
   end
-  sort!(recs, by = r -> r.game_id)
-  games == 1 ? recs[1] : recs
+  sort!(players, by = r -> r.game_id)
+  games === nothing ? players[1] : players
 end
 
-# extract_data(player) -> (positions, pis, results), mcts_play.jl:126-139: positions are rebuilt by
-# replaying the moves from the empty board, every result entry is the final game result.
-function extract_data(env::GoEnv, rec::GameRecord)
-  positions = Position[]
-  pos = Position(env)
-  for f in rec.moves
-    push!(positions, pos)
-    pos = play_move!(pos, from_flat(f, env))
+# get_replay_batch(pos_buffer, π_buffer, res_buffer; batch_size), src/train.jl:4-12: batch_size distinct entries,
+# π as an A x B matrix
+function get_replay_batch(pos_buffer::Vector{Position}, π_buffer, res_buffer; batch_size = 32)
+  picks = randperm(length(pos_buffer))[1:batch_size]             # sample(1:n, batch_size, replace = false)
+  pos_buffer[picks], reduce(hcat, π_buffer[picks]), res_buffer[picks]
+end
+
+# _train(nn, (positions, π, z), opt; epochs), src/neural_net.jl:85-101 (call: train.jl:70) as intended -- the
+# reference's does not run at HEAD (SURVEY.md D3): minibatches of 32 positions, each ONE agz_train_step on the device
+# (training-mode forward, 0.01 crossentropy + 0.01 mse + 1e-4 sum(θ²), backward, Momentum update of nn in place).
+# Returns the summed minibatch loss / epochs (:98-100).  Momentum(η, ρ = 0.9) stands for Flux.Momentum (train.jl:54):
+# its velocity lives in the network's engine.
+struct Momentum
+  eta::Float32
+  rho::Float32
+end
+Momentum(eta = 0.01f0) = Momentum(eta, 0.9f0)
+
+function _train(nn::NeuralNet, input_data, opt::Momentum; epochs = 1)
+  positions, π, z = input_data
+  env = nn.env; N = env.N; n = length(positions)
+  boards = cat(dims = 3, (p.board for p in positions)...)
+  deltas = zeros(Int8, N, N, 7, n); nd = zeros(Int32, n)
+  for (b, p) in enumerate(positions)
+    k = size(p.board_deltas, 3); nd[b] = k
+    deltas[:, :, 1:k, b] .= p.board_deltas
   end
-  positions, deepcopy(rec.searches_π), fill(rec.result, length(rec.moves))
+  tp = Int8[p.to_play for p in positions]
+  feats = zeros(Float32, N * N * 17, n)
+  check(nn.engine, ccall((:agz_features, libagz), Int32,
+        (Ptr{Cvoid}, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Ptr{Int8}, Int32, Ptr{Float32}),
+        nn.engine.handle, boards, deltas, nd, tp, n, feats))
+  cuts = vcat(collect(1:32:n), n + 1)
+  length(cuts) > 2 && cuts[end] - cuts[end-1] == 1 && deleteat!(cuts, length(cuts) - 1)   # BatchNorm needs two rows
+  loss_avg = 0f0
+  for _ in 1:epochs, j in 1:length(cuts)-1
+    r = cuts[j]:cuts[j+1]-1
+    loss_avg += train_step!(nn.engine, feats[:, r], Matrix{Float32}(π[:, r]), Float32.(z[r]); eta = opt.eta, rho = opt.rho)[1]
+  end
+  loss_avg / epochs
 end
 
 # every (layer, kind) of a network with `t` residual blocks (ids as in include/agz.h)
@@ -659,9 +811,9 @@ end
 
 # ------------------------------------------------------------------ replay batches
 # get_replay_batch(pos_buffer, π_buffer, res_buffer; batch_size), src/train.jl:4-12, with the
-# positions kept as move lists: `games[g]` is a GameRecord, a sample is (g, ply) with ply = 0 the
+# positions kept as move lists: `games[g]` is a SelfPlayPlayer, a sample is (g, ply) with ply = 0 the
 # empty board.  Returns the N x N x 17 x B feature tensor get_feats would build, π (A x B), results.
-function get_replay_batch(e::Engine, env::GoEnv, games::Vector{GameRecord}, samples::Vector{Tuple{Int,Int}})
+function get_replay_batch(e::Engine, env::GoEnv, games::Vector{SelfPlayPlayer}, samples::Vector{Tuple{Int,Int}})
   used = sort(unique(first.(samples)))
   offs = Dict{Int,Int32}(); moves = Int16[]
   for g in used

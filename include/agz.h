@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AGZ_VERSION 101
+#define AGZ_VERSION 102
 
 typedef int32_t agz_status;
 #define AGZ_OK 0
@@ -218,13 +218,16 @@ typedef struct {
   int64_t peak_nodes_per_game; /* largest tree any slot has held at the moment it moved (of max_nodes_per_game) */
   int64_t stalled_games;       /* slots waiting on a full pool right now (AGZ_POOL_STALL, or no visited child to play) */
   int64_t node_capacity;       /* max_nodes_per_game in effect */
+  int64_t abandoned_games;     /* games given up by agz_slot_abandon: they produce no record, so a run started with
+                                * agz_selfplay_start(total) is over when games_finished + abandoned_games == total */
 } agz_stats;
 agz_status agz_engine_stats(agz_engine* e, agz_stats* out);            /* synchronises */
 /* Per slot (arrays of `games` int32, any of them may be NULL): status = AGZ_OK or AGZ_POOL_EXHAUSTED (the game is
  * waiting on a full node pool: agz_config.pool_policy), nodes its tree holds, moves it has played.  The reference has
  * no analogue (its tree is unbounded, mcts.jl:140-147, mcts_play.jl:48); synchronises. */
 agz_status agz_slot_status(agz_engine* e, int32_t* status_out, int32_t* nodes_out, int32_t* moves_out);
-/* give up the game in `slot` without a record; the slot starts the next game id at the next step */
+/* give up the game in `slot` without a record (counted in agz_stats.abandoned_games; its game id is not played again); the
+ * slot starts the next game id at the next step */
 agz_status agz_slot_abandon(agz_engine* e, int32_t slot);
 /* external-network mode (MCTSPlayer.network duck typing, mcts_play.jl:5,89): after a step's
  * select phase the caller reads the leaf feature tensor and supplies pi/v. */
@@ -389,6 +392,15 @@ agz_status agz_tree_search(agz_engine* e, int32_t g, int32_t parallel_readouts, 
  * and v (nleaves); pi == NULL makes the engine evaluate the leaves with its own network */
 agz_status agz_tree_search_select(agz_engine* e, int32_t g, int32_t parallel_readouts, int32_t* nleaves_out);
 agz_status agz_tree_leaf_features(agz_engine* e, int32_t g, float* feats_out);
+/* ... or read the leaves as the `Vector{Position}` the reference hands its network (`mcts_player.network([leaf.position
+ * for leaf in leaves])`, mcts_play.jl:89; DummyNet sizes its answer by length(positions), test/test_mcts_player.jl:25-32):
+ * per collected leaf, in collection order, the GoPosition fields of board.jl:271-306 -- nodes_out int32[B] (the leaf's
+ * node handle), boards_out int8[B][N*N], deltas_out int8[B][7][N*N] (board_deltas newest first, zero beyond ndeltas),
+ * ndeltas_out int32[B], to_play_out int8[B] (together the SoA agz_net_forward / agz_features take), info_out[B] (n, ko,
+ * caps, last two moves, komi; history_len = ndeltas).  Any output may be NULL.  Valid between agz_tree_search_select and
+ * agz_tree_search_incorporate. */
+agz_status agz_tree_leaf_positions(agz_engine* e, int32_t g, int32_t* nodes_out, int8_t* boards_out, int8_t* deltas_out,
+                                   int32_t* ndeltas_out, int8_t* to_play_out, agz_position_info* info_out);
 agz_status agz_tree_search_incorporate(agz_engine* e, int32_t g, const float* pi, const float* v);
 agz_status agz_tree_pick_move(agz_engine* e, int32_t g, int32_t* a_out);
 agz_status agz_tree_play_move(agz_engine* e, int32_t g, int32_t a, int32_t* ok_out);

@@ -73,7 +73,7 @@ class GameState(C.Structure):
                 ("leaf_base", C.c_int32), ("resign_disabled", C.c_int32), ("err", C.c_int32),
                 ("result", C.c_int32), ("was_resign", C.c_int32), ("nodes_used", C.c_int32),
                 ("short_first", C.c_int32), ("arena_k", C.c_int32), ("garbage", C.c_int32), ("npend", C.c_int32),
-                ("short_searches", C.c_int32), ("pad", C.c_int32)]
+                ("short_searches", C.c_int32), ("stalled", C.c_int32)]
 
 
 class TreeArgs(C.Structure):

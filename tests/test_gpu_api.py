@@ -289,3 +289,97 @@ def test_softpick_assertion_matches_the_reference_failure():
     st, a = e.pick_move(0)
     assert st == ag._lib.OK and a == 17
     assert player.pick_move() == ag.from_flat(17, env)
+
+
+def test_external_network_receives_a_vector_of_positions_like_the_reference():
+    """mcts_play.jl:89: `mcts_player.network([leaf.position for leaf in leaves])` -- the duck-typed network gets B
+    Position objects (len(positions) = B, test/test_mcts_player.jl:25-32), each with the GoPosition fields of the leaf:
+    they equal the positions the host builds by playing the leaf's moves from the root position."""
+    env = GoEnv(N)
+    pos = Position(env)
+    for c in [(2, 2), (6, 6), (2, 6), (6, 2), (4, 4), (3, 3), (5, 5), (1, 1), (7, 7), (0, 1), (1, 0)]:
+        pos = pos.play_move(c)
+    seen = []
+
+    class Spy(DummyNet):
+        def __call__(self, positions):
+            assert isinstance(positions, list) and all(isinstance(p, Position) for p in positions)
+            seen.append(positions)
+            return super().__call__(positions)            # sized by len(positions), like the reference's DummyNet
+
+    player = MCTSPlayer(env, Spy(env))
+    player.initialize_game(pos)
+    for _ in range(6):
+        leaves = player.tree_search(8)
+        assert len(leaves) == len(seen[-1]) and all(l == p.node for l, p in zip(leaves, seen[-1]))
+    assert sum(len(b) for b in seen) >= 20 and max(len(b) for b in seen) == 8
+    root = player.root
+    for batch in seen:
+        for leaf in batch:
+            path, node = [], leaf.node
+            while node != root:                              # the leaf's moves, root first
+                path.append(node.fmove)
+                node = NodeViewParent(node)
+            want = pos
+            for a in reversed(path):
+                want = want.play_move(ag.from_flat(int(a), env))
+            assert (leaf.board == want.board).all() and leaf.n == want.n and leaf.to_play == want.to_play
+            assert leaf.caps == want.caps and leaf.ko == want.ko and leaf.komi == want.komi
+            assert leaf.board_deltas.shape == want.board_deltas.shape and (leaf.board_deltas == want.board_deltas).all()
+            assert 1 <= len(leaf.recent) <= 2 and leaf.recent == want.recent[-len(leaf.recent):]     # the last move(s) the tree holds
+            assert (ag.get_feats(leaf) == ag.get_feats(want)).all()
+
+
+def NodeViewParent(node):
+    return ag.api.NodeView(node._p, node._info.parent)
+
+
+def test_a_wrapped_neuralnet_as_external_network_builds_the_same_tree_as_the_resident_one():
+    """the Vector{Position} seam end to end: MCTSPlayer(env, nn) evaluates leaves on the device; MCTSPlayer(env, f) with
+    f = positions -> nn(positions) goes leaf positions -> host -> agz_net_forward -> host -> incorporate.  Same tree."""
+    env = GoEnv(5)
+    nn = NeuralNet(env, tower_height=1, seed=3)
+    calls = []
+
+    def wrapped(positions):
+        calls.append(len(positions))
+        return nn(positions)
+
+    a = MCTSPlayer(env, nn, num_readouts=32)
+    b = MCTSPlayer(env, wrapped, num_readouts=32)
+    for p in (a, b):
+        p.initialize_game()
+    for _ in range(10):
+        la, lb = a.tree_search(), b.tree_search()
+        assert [x.id for x in la] == [x.id for x in lb]
+    assert calls and (a.root.child_N == b.root.child_N).all() and (a.root.child_W == b.root.child_W).all()
+    assert a.root.N == b.root.N and a.pick_move() == b.pick_move()
+
+
+def test_tracker_style_network_results_are_unwrapped():
+    """mcts_play.jl:90: `move_probs, values = move_probs.data, values.data` -- a network may answer with objects carrying
+    `.data` (the reference's DummyNet returns `param(...)`, test/test_mcts_player.jl:22-32)"""
+    env = GoEnv(N)
+
+    class Tracked:
+        def __init__(self, data):
+            self.data = data
+
+    class TrackedNet(DummyNet):
+        def __call__(self, positions):
+            p, v = super().__call__(positions)
+            return Tracked(p), Tracked(v)
+
+    player = MCTSPlayer(env, TrackedNet(env, fake_value=0.17))
+    player.initialize_game()
+    player.tree_search(4)
+    assert player.root.N == 1 and player.root.Q == pytest.approx(0.085)
+
+    class WrongShape(DummyNet):                              # a network sized by anything but len(positions) fails loudly
+        def __call__(self, positions):
+            return np.ones((env.action_space, 3)) / env.action_space, np.zeros(3)
+
+    bad = MCTSPlayer(env, WrongShape(env))
+    bad.initialize_game()
+    with pytest.raises(AssertionError):
+        bad.tree_search(1)

@@ -133,39 +133,3 @@ def test_api_precision_switch():
     pi, v = nn(ag.Position(env))
     assert abs(pi.sum() - 1) < 1e-5 and -1 <= v <= 1
     nn.engine.close()
-
-
-_FORM_SCRIPT = r"""
-import hashlib, sys
-import numpy as np
-sys.path.insert(0, {root!r})
-import alphago_jl_amd as ag
-out = []
-for N, tower, B in ((9, 3, 300), (19, 3, 40), (13, 2, 33)):
-    eng = ag.Engine(board_size=N, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
-    eng.init_synthetic(5)
-    eng.set_precision("f16")
-    feats = (np.random.RandomState(N).rand(B, 17 * N * N) < 0.3).astype(np.float32)
-    pi, v = eng.forward_features(feats)
-    out.append(hashlib.sha256(pi.tobytes() + v.tobytes()).hexdigest())
-    eng.close()
-print("FORMS", " ".join(out))
-"""
-
-
-def test_the_two_forms_of_the_half_layers_are_bit_identical():
-    """Round 5: the half-in / half-out layers run on k_conv3x3_f16_q (2 x 2 waves over 256 x 256 tiles); AGZ_C16_Q=0 runs them
-    on the 7 x 2 form that still serves the f32-residual / f32-output layers, AGZ_C16_Q=2 mixes them.  Same reduction order
-    per output (chunk, tap, k): the network's outputs must be the same BITS whichever form ran -- which is also what keeps
-    tree parity independent of the form.  (The switch is read once per process, hence the subprocesses.)"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    got = {}
-    for q in ("0", "1", "2"):
-        r = subprocess.run([sys.executable, "-c", _FORM_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, AGZ_C16_Q=q), cwd=root)
-        assert r.returncode == 0, r.stderr[-1500:]
-        got[q] = [l for l in r.stdout.splitlines() if l.startswith("FORMS")][0]
-    assert got["0"] == got["1"] == got["2"], got

@@ -93,7 +93,32 @@ def test_stall_policy_waits_instead_of_shortening():
         before = sim.game(g).move_count
         for _ in range(20):
             sim.step(net.on_feats)
-        assert sim.game(g).move_count == before and sim.game(g).err == POOL_EXHAUSTED
+        assert sim.game(g).move_count == before and sim.game(g).err == POOL_EXHAUSTED and sim.game(g).stalled == 1
     assert all(r["short_searches"] == 0 for r in sim.records())
+    sim.close()
+    net.close()
+
+
+def test_move_early_games_are_never_reported_as_stalled_between_steps():
+    """G.err stays AGZ_POOL_EXHAUSTED from a refused allocation until the NEXT step's pre phase
+    plays the early move, so `err == EXHAUSTED and phase == SEARCH` -- what agz_stats.stalled_games counted -- was true
+    between steps for games that were not waiting at all, and api.selfplay / check_pool / bench.py aborted in exactly
+    the case the default policy survives.  `stalled` is set by game_pre only when the game could NOT move early: polled
+    after every step of a starved run it is never set under AGZ_POOL_MOVE_EARLY, while err == EXHAUSTED is seen."""
+    net = OracleNet(5, 1, seed=0)
+    sim = hs.Sim(board_size=5, games=3, num_readouts=16, seed=3, game_id_base=0, game_id_stride=1,
+                 record_capacity_games=16, max_nodes_per_game=24, pool_policy=0, resign_threshold=-2.0)
+    sim.start(6)
+    err_seen = stalled_seen = steps = 0
+    while sim.counters()["finished"] < 6 and steps < 6000:
+        sim.step(net.on_feats)
+        steps += 1
+        for g in range(3):
+            G = sim.game(g)
+            err_seen += G.err == POOL_EXHAUSTED and G.phase == 3
+            stalled_seen += G.stalled != 0
+    assert sim.counters()["finished"] == 6 and sim.counters()["pool_short"] > 0
+    assert err_seen > 0, "the run did hit the ambiguous state (err set between steps)"
+    assert stalled_seen == 0, "no game of a move-early run ever waits"
     sim.close()
     net.close()
