@@ -127,6 +127,8 @@ def load():
         "agz_net_set_precision": (i32, [E, i32]),
         "agz_profile_conv_enable": (i32, [E, i32]),
         "agz_profile_conv_read": (i32, [E, f64p, f64p, P(i64)]),
+        "agz_profile_search_enable": (i32, [E, i32]),
+        "agz_profile_search_read": (i32, [E, f64p, P(i64)]),
         "agz_go_play": (i32, [E, i8p, i8p, i32p, i32p, i32, i8p, i32p, i32p, i32p]),
         "agz_go_legal": (i32, [E, i8p, i8p, i32p, i32, i8p]),
         "agz_go_score": (i32, [E, i8p, f32p, i32, f32p]),

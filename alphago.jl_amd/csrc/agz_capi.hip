@@ -172,6 +172,15 @@ agz_status agz_profile_conv_enable(agz_engine* e, int32_t on) {
 agz_status agz_profile_conv_read(agz_engine* e, double* total_ms, double* total_flop, int64_t* launches) {
   return guard(e, [&](agz::Engine& E) { E.net().profile_read(total_ms, total_flop, launches); });
 }
+agz_status agz_profile_search_enable(agz_engine* e, int32_t on) {
+  return guard(e, [&](agz::Engine& E) { E.profile_search_enable(on != 0); });
+}
+agz_status agz_profile_search_read(agz_engine* e, double* ms5, int64_t* steps) {
+  return guard(e, [&](agz::Engine& E) {
+    AGZ_REQUIRE(ms5, AGZ_BAD_ARGUMENT, "ms5 is NULL");
+    E.profile_search_read(ms5, steps);
+  });
+}
 
 // ---- Go rules
 agz_status agz_go_play(agz_engine* e, const int8_t* boards, const int8_t* to_play, const int32_t* ko,

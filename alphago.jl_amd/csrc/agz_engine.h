@@ -84,6 +84,9 @@ class Engine {
   void features(const int8_t* boards, const int8_t* deltas, const int32_t* ndeltas, const int8_t* to_play,
                 int B, float* out);
   float time_forward(int B, int iters);
+  // HIP events around the five search kernels of the next steps (bench.py's `search_kernels`)
+  void profile_search_enable(bool on);
+  void profile_search_read(double* ms5, int64_t* steps);
   float time_conv(int B, int iters);
   void slot_status(int32_t* status, int32_t* nodes, int32_t* moves);
   void slot_abandon(int g);
@@ -130,6 +133,10 @@ class Engine {
   std::unique_ptr<Net> net_, net2_;   // net2_: White's network in arena mode
   std::unique_ptr<Trainer> trainer_, trainer2_;
   int net_sel_ = 0;
+  static constexpr int kSearchProfMax = 512;      // steps whose search kernels are timed after profile_search_enable(true)
+  bool sprof_on_ = false;
+  int sprof_n_ = 0;
+  std::vector<hipEvent_t> sprof_ev_;              // [step][7]: before k_pre, behind k_pre / k_expand / k_scan / k_leaf_features, in front of / behind k_post
   int external_batch2_ = 0;
   std::vector<void*> bufs_;
   size_t state_bytes_ = 0;

@@ -481,6 +481,7 @@ Engine::Engine(const agz_config& cfg) : cfg_(cfg) {
 
 Engine::~Engine() {
   (void)hipStreamSynchronize(stream_);
+  for (auto e : sprof_ev_) (void)hipEventDestroy(e);
   // the trainers point into their networks (host-sync callback) and own device buffers: they go first, then the
   // networks, and the stream they all enqueue on last
   trainer_.reset();
@@ -524,10 +525,17 @@ void Engine::step(int nsteps) {
               "engine was created with external_network=1: use select/incorporate");
   stepped_ = stepped_ || nsteps > 0;
   for (int s = 0; s < nsteps; ++s) {
+    // (search-kernel timing, bench.py: seven events per step on the engine's stream; off: no event is recorded)
+    hipEvent_t* ev = sprof_on_ && sprof_n_ < kSearchProfMax ? &sprof_ev_[(size_t)7 * sprof_n_] : nullptr;
+    if (ev) (void)hipEventRecord(ev[0], stream_);
     hipLaunchKernelGGL(k_pre, dim3(V_.games), dim3(kWave), 0, stream_, V_);
+    if (ev) (void)hipEventRecord(ev[1], stream_);
     hipLaunchKernelGGL(k_expand, dim3(V_.games * (kMaxPend / 2)), dim3(kWave), 0, stream_, V_);
+    if (ev) (void)hipEventRecord(ev[2], stream_);
     hipLaunchKernelGGL(cfg_.arena_mode ? k_scan_arena : k_scan, dim3(1), dim3(256), 0, stream_, V_);
+    if (ev) (void)hipEventRecord(ev[3], stream_);
     hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWave), 0, stream_, V_, 0, d_x32_.p, (float*)nullptr);
+    if (ev) (void)hipEventRecord(ev[4], stream_);
     if (cfg_.arena_mode) {   // evaluate(): Black's players ask network 0, White's network 1
       const int half = bcap_ / 2;
       net_->forward(d_x32_.p, V_.batch_count, half, d_pi_.p, d_v_.p);
@@ -536,9 +544,37 @@ void Engine::step(int nsteps) {
     } else {
       net_->forward(d_x32_.p, V_.batch_count, bcap_, d_pi_.p, d_v_.p);
     }
+    if (ev) (void)hipEventRecord(ev[5], stream_);
     hipLaunchKernelGGL(k_post, dim3(V_.games), dim3(kWave), 0, stream_, V_);
+    if (ev) {
+      (void)hipEventRecord(ev[6], stream_);
+      ++sprof_n_;
+    }
   }
   AGZ_HIP(hipGetLastError());
+}
+
+void Engine::profile_search_enable(bool on) {
+  if (on && sprof_ev_.empty()) {
+    sprof_ev_.resize((size_t)7 * kSearchProfMax);
+    for (auto& e : sprof_ev_) AGZ_HIP(hipEventCreate(&e));
+  }
+  sprof_on_ = on;
+  if (on) sprof_n_ = 0;
+}
+
+// ms5: summed milliseconds of k_pre, k_expand, k_scan, k_leaf_features, k_post over the timed steps
+void Engine::profile_search_read(double* ms5, int64_t* steps) {
+  AGZ_HIP(hipStreamSynchronize(stream_));
+  for (int k = 0; k < 5; ++k) ms5[k] = 0.0;
+  static const int a[5] = {0, 1, 2, 3, 5}, b[5] = {1, 2, 3, 4, 6};
+  for (int i = 0; i < sprof_n_; ++i)
+    for (int k = 0; k < 5; ++k) {
+      float ms = 0.f;
+      AGZ_HIP(hipEventElapsedTime(&ms, sprof_ev_[(size_t)7 * i + a[k]], sprof_ev_[(size_t)7 * i + b[k]]));
+      ms5[k] += ms;
+    }
+  if (steps) *steps = sprof_n_;
 }
 
 int Engine::select_external() {

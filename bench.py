@@ -103,8 +103,52 @@ def live_pmc_traffic(args, seconds_cap=240.0):
             d = pt.summarise(8 * args.games, args.board, dirs)
         except Exception as ex:
             return None, f"{type(ex).__name__}: {ex}"
+    live_pmc_traffic.search = d.get("search_kernels") or None      # (per-dispatch bytes of k_pre ... k_post of the same passes)
     return d["bytes_per_row"], (f"live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command on this box, "
                                 f"{d['tower_layer_dispatches']} tower-layer dispatches, {time.time() - t0:.0f} s")
+
+
+live_pmc_traffic.search = None
+
+
+def search_kernels_object(search_ms, search_steps, d, games, N, step_ms, pmc):
+    """the search / feature / legal kernels as microseconds per step and HBM GB/s (these are integer / byte
+    paths: the roofline that applies is HBM's ~8 TB/s, and for the tree walks of k_pre / k_post not even that but the latency of
+    a chain of dependent loads).  Time: HIP events on the engine's stream around each kernel of the timed steps.  Bytes:
+    `algorithmic` where the kernel has a closed form -- k_leaf_features reads 8 boards of N^2 int8 and writes N^2 x 32 f32 per
+    leaf (features.jl:3-26), k_expand reads and writes one board, one legal mask and one 32-byte node record per new leaf
+    (board.jl:451-509), k_scan one count and one base per game -- and `pmc` = FETCH_SIZE + WRITE_SIZE per dispatch from the
+    live rocprofv3 counter passes of this command (as counted: no streaming-read correction applies to 1-8 B/lane loads)."""
+    if not search_steps:
+        return None
+    P, A = N * N, N * N + 1
+    leaves = d["evals"] / max(d["steps"], 1)                     # network rows per step = leaves collected per step
+    alg = {"k_leaf_features": leaves * (8.0 * P + 128.0 * P),
+           "k_expand": leaves * (2.0 * P + 4.0 * ((A + 31) // 32) + 64.0),
+           "k_scan": games * 8.0}
+    out = {"steps_timed": search_steps, "leaves_per_step": leaves, "hbm_peak_gb_s": 8000.0, "kernels": {}}
+    tot = 0.0
+    for k, ms in search_ms.items():
+        us = 1e3 * ms / search_steps
+        tot += us
+        o = {"us_per_step": us, "share_of_step": us * 1e-3 / step_ms}
+        if k in alg:
+            o["algorithmic_bytes_per_step"] = alg[k]
+            o["algorithmic_gb_s"] = alg[k] / (us * 1e-6) / 1e9 if us > 0 else None
+            o["algorithmic_frac_of_hbm_peak"] = o["algorithmic_gb_s"] / 8000.0 if us > 0 else None
+        if pmc and k in pmc:
+            b = sum(v for c, v in pmc[k].items() if c.endswith("_bytes_per_dispatch"))
+            o["pmc_bytes_per_dispatch"] = b
+            o["pmc_gb_s"] = b / (us * 1e-6) / 1e9 if us > 0 else None
+            o["pmc_frac_of_hbm_peak"] = o["pmc_gb_s"] / 8000.0 if us > 0 else None
+        out["kernels"][k] = o
+    out["us_per_step_total"] = tot
+    out["share_of_step_total"] = tot * 1e-3 / step_ms
+    out["bound"] = ("k_pre / k_post: latency of dependent loads down one tree per wave (one round trip per tree level); "
+                    "k_expand: LDS latency of two component labellings per new leaf; k_leaf_features: HBM writes")
+    out["pmc_source"] = ("live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (the passes behind roofline.traffic)"
+                         if pmc else None)
+    return out
 
 
 class PowerSampler:
@@ -492,6 +536,7 @@ def main():
     eng.sync()
     s0 = eng.stats()
     eng.profile_conv(True)
+    eng.profile_search(True)
     sampler = PowerSampler(local_rank) if rank == 0 else None
     barrier()
     if sampler:
@@ -505,7 +550,26 @@ def main():
     barrier()
     conv_ms, conv_flop, conv_n = eng.profile_conv_read()
     eng.profile_conv(False)
+    search_ms, search_steps = eng.profile_search_read()
+    eng.profile_search(False)
     s1 = eng.stats()
+
+    # N > 1: rank 0 repeats the K steps ALONE (every other rank waits at the barrier behind it), so that the line carries
+    # the N = 1 rate of the same box and `weak_scaling_efficiency` needs no second run
+    solo = None
+    if world > 1:
+        if rank == 0:
+            eng.sync()
+            q0 = eng.stats()
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            eng.step(args.steps)
+            eng.sync()
+            torch.cuda.synchronize()
+            ts1 = time.perf_counter()
+            solo = {"positions_per_s": (eng.stats()["positions"] - q0["positions"]) / (ts1 - ts0), "seconds": ts1 - ts0,
+                    "what": f"rank 0 alone on its GPU, the same {args.steps} steps, the other ranks idle at a barrier"}
+        barrier()
 
     # Extra leg, reported beside `value`, never as it: the same K steps with the Winograd operands carried as two f16
     # halves (AGZ_PRECISION_F32S: f32 network, f32 accumulate, fp16 MFMA; agrees with the float64 oracle as closely
@@ -624,6 +688,7 @@ def main():
         def _exchange():
             try:
                 own = eng.records_count()
+                own_bytes = eng.records_packed_size()
                 if args.single_device_test:
                     barrier()
                     e0 = time.perf_counter()
@@ -641,12 +706,14 @@ def main():
                 eng.sync()
                 e1 = time.perf_counter()
                 # every rank must now hold the same arena: sum of everybody's finished games, rank order
-                chk = torch.tensor([own, added, eng.replay_positions()], dtype=torch.int64, device=rdev)
+                chk = torch.tensor([own, added, eng.replay_positions(), own_bytes], dtype=torch.int64, device=rdev)
                 allc = [torch.zeros_like(chk) for _ in range(world)]
                 dist.all_gather(allc, chk)
                 allc = [[int(v) for v in t.tolist()] for t in allc]
                 box["ok"] = {"collective": how, "games_in_arena": added, "positions_in_arena": eng.replay_positions(),
-                             "ms": 1e3 * (e1 - e0), "own_games": own, "own_games_by_rank": [c[0] for c in allc],
+                             "ms": 1e3 * (e1 - e0), "bytes": sum(c[3] for c in allc), "bytes_by_rank": [c[3] for c in allc],
+                             "gb_s_into_each_arena": sum(c[3] for c in allc) / max(e1 - e0, 1e-9) / 1e9,
+                             "own_games": own, "own_games_by_rank": [c[0] for c in allc],
                              "consistent": all(c[1] == sum(x[0] for x in allc) and c[2] == allc[0][2] for c in allc)}
                 eng.records_clear()
                 if not args.single_device_test:
@@ -788,10 +855,30 @@ def main():
             roofline["at_measured_clock"] = {"sclk_mhz": mhz, "peak": peak * mhz / 2400.0,
                                              "frac": exe_tf / (peak * mhz / 2400.0), "unit": "TFLOP/s",
                                              "note": "peak scaled from the 2.4 GHz nominal clock to the mean sampled sclk"}
+        if search_steps:
+            out["search_kernels"] = search_kernels_object(search_ms, search_steps, d if world == 1 else {**d, "evals": d["evals"] / world},
+                                                          args.games, N, 1e3 * elapsed / args.steps, live_pmc_traffic.search)
         if generation is not None:
             out["generation"] = generation
+            if not generation["capped"]:
+                # SURVEY.md 8d's definition of the metric is the generation rate (sum of position.n of the games that ENDED in a
+                # whole generation after a warm-up generation / wall time): when that leg ran to its end it IS `value`
+                # (VERDICT r5 #4); the K-step window stays in the line as `steady_state` and behind ms_per_step / steps / warmup
+                out["steady_state"] = {"value": value, "unit": "positions/s", "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
+                                       "what": "moves that completed their full readout budget inside the K timed steps / their time "
+                                               "(every game mid-search at a random phase; no game ends in the window)"}
+                out["value"] = generation["generation_rate"]
+                out["value_definition"] = ("generation.generation_rate: sum of the lengths of the games that ended in the measured "
+                                           "generation / its wall time (SURVEY.md 8d; selfplay.jl:22-43), on the same engine right behind "
+                                           "the K timed steps; ms_per_step, steps, warmup and roofline describe the K-step window "
+                                           "(`steady_state`)")
+                out["end_to_end_algorithmic_tflops"] = out["value"] * fpos / world / 1e12
+                out["end_to_end_executed_mfma_frac"] = out["value"] * fpos * wino_ratio / (world * peak * 1e12)
         if per_rank is not None:
             out["per_rank"] = per_rank      # each rank's own clock over the same K steps (`value` uses the slowest)
+            if solo is not None:
+                out["single_rank_same_box"] = solo
+                out["weak_scaling_efficiency"] = min(r["positions_per_s"] for r in per_rank) / solo["positions_per_s"]
         if exchange is not None:
             out["exchange"] = exchange
         if alt is not None:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AGZ_VERSION 102
+#define AGZ_VERSION 103
 
 typedef int32_t agz_status;
 #define AGZ_OK 0
@@ -176,6 +176,13 @@ agz_status agz_net_set_precision(agz_engine* e, int32_t precision);
  * each launch actually processed) and the launch count. */
 agz_status agz_profile_conv_enable(agz_engine* e, int32_t on);
 agz_status agz_profile_conv_read(agz_engine* e, double* total_ms, double* total_flop, int64_t* launches);
+/* The same for the search kernels of agz_selfplay_step (SURVEY.md 8d asks for them as HBM GB/s beside the tower's
+ * TFLOP/s): HIP events on the engine's stream around k_pre (select_leaf / pick_move / play_move!, mcts.jl:108-138,
+ * mcts_play.jl:52-71,126-139), k_expand (maybe_add_child!'s play_move!, mcts.jl:140-147, board.jl:451-509), k_scan,
+ * k_leaf_features (features.jl:3-26) and k_post (incorporate_results! / backup_value!, mcts.jl:186-225) of the next
+ * <= 512 steps.  read() synchronises; ms5 = summed milliseconds in that order. */
+agz_status agz_profile_search_enable(agz_engine* e, int32_t on);
+agz_status agz_profile_search_read(agz_engine* e, double* ms5 /* [5] */, int64_t* steps);
 
 /* ---------------------------------------------------------------- Go rules (batched) --- */
 /* play_move!(pos, c), board.jl:451-509 / pass_move! :426-440.  In/out SoA per position:

@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol():
     # and the python binding declares a prototype for each of them
     unbound = [n for n in names if n not in L._agz_signatures]
     assert not unbound, unbound
-    assert L.agz_version() == 102
+    assert L.agz_version() == 103
 
 
 def test_config_default_mirrors_reference_defaults():

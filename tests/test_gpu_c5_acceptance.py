@@ -1,0 +1,138 @@
+"""configs[4] (GoEnv(19), tower 20, fp16 MFMA tower): what the mixed-precision network does to the quantities the path
+is FOR -- the moves self-play selects and the visit distributions it records -- next to the error of the tensors.
+
+`north_star` states a tolerance for the exact-f32 path only (policy / value within 1e-4); for the fp16 tower it says
+"mixed-precision inference".  tests/test_gpu_configs.py holds the tensors to 1e-2 against float64 at 40 convolutions and
+measures 8e-3: a bar chosen by the builder and nearly used up.  This file adds the acceptance that
+means something for self-play (/root/reference/src/mcts_play.jl:52-71 picks a move from the visit counts; selfplay.jl
+records pi = the visit distribution):
+
+  (a) error against depth: towers of 1, 5, 10 and 20 blocks, 256 positions of 19x19, fp16 tower against the exact network.
+      The exact network is the engine's own f32 path, itself checked against the float64 oracle on a subset in this test
+      (<= 1e-6: four decades below anything measured here), so that 256 positions at tower 20 do not cost the CPU 4 TFLOP
+      of float64;
+  (b) whole-game behaviour: the same 32 games (same seed, same weights, same draw stream) played by an f32 engine and an
+      fp16 engine at the shard's settings scaled down in readouts; for every move made from an IDENTICAL history (a game
+      leaves the comparison at its first differing move): does fp16 select the same move, is the top-1 of the recorded
+      pi the same, and KL(pi_f32 || pi_f16) of the recorded visit distributions;
+  (c) the 1e-2 tensor bar stays, as the secondary one (test_gpu_configs.py).
+
+Bars (stated here, measured values are printed by the test and quoted in DESIGN.md section 4):
+  depth curve    max |d pi|, |d v| <= 1.5e-3 (t = 1), 4e-3 (5), 6e-3 (10), 1e-2 (20); never shrinking bar with depth
+  games          selected move identical on >= 0.90 of the compared moves; top-1 of pi identical on >= 0.85;
+                 mean KL(pi_f32 || pi_f16) <= 2e-2 nats, 95th percentile <= 8e-2
+"""
+import numpy as np
+import pytest
+
+import alphago_jl_amd as ag
+import orc
+from gpu_common import copy_weights_from_oracle, pos_soa
+from test_gpu_nn import oracle_forward64
+from test_hostsim_go import random_positions
+from test_oracle_nn import randomize_bn
+
+pytestmark = pytest.mark.gpu
+L = orc.lib()
+N19 = 19
+DEPTH_BARS = {1: 1.5e-3, 5: 4e-3, 10: 6e-3, 20: 1e-2}
+BAR_SAME_MOVE, BAR_SAME_TOP1, BAR_KL_MEAN, BAR_KL_P95 = 0.90, 0.85, 2e-2, 8e-2
+
+
+def _net(tower, seed):
+    rng = np.random.RandomState(seed)
+    onet = L.or_net_new(N19, tower)
+    L.or_net_init_synthetic(onet, 3)
+    randomize_bn(onet, list(range(0, 1 + 2 * tower)) + [orc.L_VALUE_CONV, orc.L_POLICY_CONV], rng)
+    return onet, rng
+
+
+def test_c5_error_against_depth():
+    B, A = 256, N19 * N19 + 1
+    pool = random_positions(N19, 8, 150, seed=21)
+    curve = []
+    for tower in (1, 5, 10, 20):
+        onet, rng = _net(tower, 100 + tower)
+        positions = [pool[i] for i in rng.choice(len(pool), B, replace=False)]
+        eng = ag.Engine(board_size=N19, games=1, tower_height=tower, num_readouts=8, max_nodes_per_game=16)
+        copy_weights_from_oracle(eng, onet, tower)
+        soa = pos_soa(positions)
+        pi32, v32 = eng.forward(*soa)
+        eng.set_precision("f16")
+        pi16, v16 = eng.forward(*soa)
+        # the exact network behind the comparison: the f32 path against float64 on 8 of the positions
+        sub = list(range(0, B, B // 8))
+        feats = np.stack([orc.feats(positions[i]).reshape(-1) for i in sub])
+        pi64, v64 = oracle_forward64(onet, feats, A)
+        d32 = max(np.abs(pi32[sub] - pi64).max(), np.abs(v32[sub] - v64).max())
+        assert d32 <= 1e-6, (tower, d32)
+        dpi, dv = float(np.abs(pi16 - pi32).max()), float(np.abs(v16 - v32).max())
+        kl = float(np.mean(np.sum(pi32 * (np.log(np.maximum(pi32, 1e-30)) - np.log(np.maximum(pi16, 1e-30))), axis=1)))
+        top1 = float(np.mean(pi16.argmax(1) == pi32.argmax(1)))
+        curve.append((tower, dpi, dv, kl, top1, d32))
+        print(f"19x19 tower {tower:2d}, {B} positions, fp16 tower vs exact: max|dpi| {dpi:.2e}  max|dv| {dv:.2e}  "
+              f"mean KL(pi32||pi16) {kl:.2e}  network top-1 agrees {top1:.3f}   (f32 path vs float64 on {len(sub)}: {d32:.1e}; "
+              f"pi max {pi32.max():.3f})")
+        assert max(dpi, dv) <= DEPTH_BARS[tower], (tower, dpi, dv)
+        L.or_net_free(onet)
+        eng.close()
+    assert len(curve) == 4
+
+
+def _play(precision, onet, tower, G, R, moves, seed):
+    eng = ag.Engine(board_size=N19, tower_height=tower, games=G, num_readouts=R, parallel_readouts=8, seed=seed,
+                    resign_threshold=-2.0)            # (no resignation: every game reaches `moves`)
+    copy_weights_from_oracle(eng, onet, tower)
+    eng.set_precision(precision)
+    eng.start(0)
+    per_move = (R + 7) // 8
+    for _ in range(4 * moves):
+        eng.step(per_move)
+        if min(eng.debug_live_record(g)[1] for g in range(G)) >= moves:
+            break
+    out = []
+    for g in range(G):
+        gid, nm = eng.debug_live_record(g)
+        assert nm >= moves, (g, nm)
+        recs = [eng.debug_live_record(g, k) for k in range(moves)]
+        out.append((gid, [r[2] for r in recs], np.stack([r[3] for r in recs])))
+    st = eng.stats()
+    assert st["pool_short_searches"] == 0 and st["games_finished"] == 0
+    eng.close()
+    return out
+
+
+def test_c5_whole_games_select_the_moves_the_f32_tower_selects():
+    tower, G, R, moves = 20, 32, 400, 20
+    onet, _ = _net(tower, 321)
+    a = _play("f32", onet, tower, G, R, moves, seed=7)
+    b = _play("f16", onet, tower, G, R, moves, seed=7)
+    L.or_net_free(onet)
+    same_move = same_top1 = compared = 0
+    kls, first_div = [], []
+    for (ga, ma, pa), (gb, mb, pb) in zip(a, b):
+        assert ga == gb
+        div = moves
+        for k in range(moves):
+            compared += 1
+            p, q = pa[k].astype(np.float64), pb[k].astype(np.float64)
+            assert abs(p.sum() - 1) < 1e-4 and abs(q.sum() - 1) < 1e-4
+            m = p > 0
+            kls.append(float(np.sum(p[m] * (np.log(p[m]) - np.log(np.maximum(q[m], 1.0 / (4.0 * R)))))))
+            same_top1 += int(p.argmax() == q.argmax())
+            if ma[k] == mb[k]:
+                same_move += 1
+            else:
+                div = k
+                break
+        first_div.append(div)
+    kls = np.array(kls)
+    frac_move, frac_top1 = same_move / compared, same_top1 / compared
+    print(f"19x19 tower {tower}, {G} games x {moves} moves, {R} readouts, f32 vs fp16 tower from identical histories: "
+          f"{compared} moves compared, selected move identical {frac_move:.3f} (bar {BAR_SAME_MOVE}), top-1 of pi identical "
+          f"{frac_top1:.3f} (bar {BAR_SAME_TOP1}), KL(pi32||pi16) mean {kls.mean():.2e} p95 {np.percentile(kls, 95):.2e} max {kls.max():.2e} "
+          f"(bars {BAR_KL_MEAN}, {BAR_KL_P95}); games identical for all {moves} moves: {sum(d == moves for d in first_div)}/{G}, "
+          f"first difference at move (median) {int(np.median(first_div))}")
+    assert frac_move >= BAR_SAME_MOVE, frac_move
+    assert frac_top1 >= BAR_SAME_TOP1, frac_top1
+    assert kls.mean() <= BAR_KL_MEAN and np.percentile(kls, 95) <= BAR_KL_P95, (kls.mean(), np.percentile(kls, 95))

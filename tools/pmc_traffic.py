@@ -52,6 +52,14 @@ def summarise(B, N, dirs):
             per_kernel[k]["FETCH_SIZE"] *= 2.0
         if not stem:
             total += sum(v for c, v in per_kernel[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE"))
+    # the search kernels of a step ("search / feature / legal kernels reported as HBM GB/s"): bytes per dispatch,
+    # FETCH_SIZE as counted (their loads are 1-8 B per lane, not the 16 B/lane streaming reads the x2 rule is calibrated on)
+    search = {}
+    for k, cs in agg.items():
+        short = k.replace("agz::", "")
+        if short in ("k_pre", "k_expand", "k_scan", "k_leaf_features", "k_post"):
+            n = max(len(v) for v in cs.values())
+            search[short] = {"dispatches": n, **{c + "_bytes_per_dispatch": 1024.0 * sum(v) / len(v) for c, v in cs.items()}}
     have = {c for cs in per_kernel.values() for c in cs}
     if not layers or not {"FETCH_SIZE", "WRITE_SIZE"} <= have:
         raise RuntimeError(f"no tower-layer dispatches with both counters under {dirs} (have {sorted(have)}, {layers} layers)")
@@ -61,7 +69,7 @@ def summarise(B, N, dirs):
                   "tower-layer Winograd kernels of the run / number of tower-layer GEMM dispatches (the stem's 8-stage GEMM is listed, not counted)",
         "rows_per_launch": rows, "tower_layer_dispatches": layers, "bytes_per_launch": total / layers, "bytes_per_row": total / layers / rows,
         "algorithmic_bytes_per_row": 2.5 * 256 * 4, "board": N,
-        "per_kernel_total_bytes": per_kernel, "per_kernel_dispatches": counts,
+        "per_kernel_total_bytes": per_kernel, "per_kernel_dispatches": counts, "search_kernels": search,
     }
 
 
