@@ -148,7 +148,7 @@ agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_
 }
 
 agz_status agz_net_set_winograd(agz_engine* e, int32_t on) {
-  return guard(e, [&](agz::Engine& E) { AGZ_REQUIRE(on >= 0 && on <= 2, AGZ_BAD_ARGUMENT, "agz_net_set_winograd: 0, 1 or 2"); E.net().set_winograd(on); });
+  return guard(e, [&](agz::Engine& E) { AGZ_REQUIRE(on >= 0 && on <= 3, AGZ_BAD_ARGUMENT, "agz_net_set_winograd: 0, 1, 2 or 3"); E.net().set_winograd(on); });
 }
 agz_status agz_net_set_tower_persistent(agz_engine* e, int32_t on) {
   return guard(e, [&](agz::Engine& E) { E.net().set_tower_persistent(on != 0); });

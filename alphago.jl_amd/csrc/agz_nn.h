@@ -26,6 +26,7 @@ struct DenseHost {
 };
 
 bool wino4_applies(int N);      // agz_wino4.hip (declared with the rest of its interface below)
+bool wino5_applies(int N);      // agz_wino5.hip
 
 class Net {
  public:
@@ -65,7 +66,10 @@ class Net {
 
   // tower convolution algorithm: 1 = Winograd (default: F(3x3,3x3), and F(4x4,3x3) for boards of 13x13 and larger in the
   // exact-f32 arithmetic), 2 = Winograd F(3x3,3x3) on every board size (A/B runs), 0 = the direct implicit GEMM
-  void set_winograd(int mode) { winograd_ = mode != 0; wino_f33_only_ = mode == 2; }
+  // 3 = 1 with the tower layers of small boards (whole-board tile blocks, N <= 12) on the five-pass 64 x 128 form of
+  // F(3x3,3x3) (agz_wino5.hip) instead of k_wino_gemm4
+  void set_winograd(int mode) { winograd_ = mode != 0; wino_f33_only_ = mode == 2; wino5_ = mode == 3; }
+  bool use_wino5() const { return winograd_ && wino5_ && precision_ == 0 && tower_ > 0 && wino5_applies(N_); }
   bool winograd() const { return winograd_; }
   // The Winograd tower of a large batch as n independent layer chains (ranges of its tile blocks, cut at board boundaries)
   // on n streams: the hardware scheduler interleaves their workgroups, the CUs stop marching through K loops and store
@@ -136,7 +140,9 @@ class Net {
   // workspace
   int bcap_ = 0;
   DevBuf<float> d_a_, d_b_, d_t_, d_vh_, d_ph_;
-  bool winograd_ = true, wino_f33_only_ = false;
+  bool winograd_ = true, wino_f33_only_ = false, wino5_ = false;
+  DevBuf<float> d_uwino5_;                     // five-pass F(3x3,3x3) weights (agz_wino5.hip), packed when first used
+  bool packed5_ = false;
   DevBuf<float> d_uwino4_;                     // F(4x4,3x3) transformed weights (agz_wino4.hip), packed when first used
   bool packed4_ = false;
   static constexpr int kMaxTowerStreams = 4;
@@ -237,6 +243,16 @@ constexpr int kWinoTowerErrWord = 8;         // int offset of the scheduler's er
 // split-operand form (AGZ_PRECISION_F32S): weights as (hi, lo) halves of 2^10 u; 1 / (operand scales) for the epilogue
 void wino_pack_weights_split(const ConvHost& c, float* out, int ns = kWinoStages);
 float wino_split_descale();
+
+// Winograd F(3x3,3x3) tower layer in five one-row passes over a 64-tile x 128-cout workgroup tile (agz_wino5.hip): reads the
+// V images of agz_wino.hip's kernels, its own U image; whole-board tile blocks (N <= 12), exact f32
+bool wino5_applies(int N);
+void wino5_pack_weights(const ConvHost& c, float* out);                              // host restatement (test reference)
+void launch_wino5_pack(const float* d_w, long wstride, int layers, float* d_out, hipStream_t s);
+size_t wino5_weight_floats();
+void launch_wino5_gemm(const float* vimg, const float* uimg, const float* scale, const float* shift, const float* res,
+                       float* y, float* vnext, const int* d_count, int bcap, int N, int relu, hipStream_t s, int part = 0,
+                       int parts = 1);
 
 // Winograd F(4x4,3x3) tower convolution for boards of 13x13 and larger (agz_wino4.hip): 36 planes in six one-row passes over
 // the input channels, each folded into the inverse transform when its K loop ends; tiles of 4x4 outputs, T = ceil(N / 4)

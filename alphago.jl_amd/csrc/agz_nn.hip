@@ -600,7 +600,12 @@ void Net::pack() {
   const size_t w0 = flux_offset(0, AGZ_K_WEIGHT);
   const size_t w1 = tower_ > 0 ? flux_offset(1, AGZ_K_WEIGHT) : 0;
   const long tstride = tower_ > 0 ? (long)(flux_offset(2, AGZ_K_WEIGHT) - w1) : 0;      // tower layers (2 per block) are equally spaced
-  if (derived_dirty_) { packed4_ = packed16_ = packed_split_ = false; }
+  if (derived_dirty_) { packed4_ = packed5_ = packed16_ = packed_split_ = false; }
+  if (use_wino5() && !packed5_) {
+    d_uwino5_.ensure(wino5_weight_floats() * 2 * tower_);
+    launch_wino5_pack(F + w1, tstride, 2 * tower_, d_uwino5_.p, stream_);
+    packed5_ = true;
+  }
   if (precision_ == 2 && tower_ > 0 && !packed_split_) {
     d_uwino_s_.ensure(wino_weight_floats() * 2 * tower_);
     launch_wino_pack(F + w1, tstride, kC, 2 * tower_, d_uwino_s_.p, kWinoStages, true, stream_);
@@ -711,6 +716,13 @@ long Net::debug_pack_diff(int which) {
         for (int o = 0; o < kC; ++o) sc[(size_t)l * kC + o] *= wino_split_descale();
       }
       return bad + diff(d_scale_s_.p, sc.data(), sc.size() * 4);
+    }
+    case 6: {      // five-pass F(3x3,3x3) images (agz_net_set_winograd(3))
+      if (!use_wino5()) return 0;
+      long bad = 0;
+      std::vector<float> u(wino5_weight_floats());
+      for (int l = 0; l < 2 * tower_; ++l) { wino5_pack_weights(tconv_[l], u.data()); bad += diff(d_uwino5_.p + u.size() * l, u.data(), u.size() * 4); }
+      return bad;
     }
     case 5: {      // folded affines + head block
       std::vector<float> scale((size_t)L * kC), shift((size_t)L * kC);
@@ -974,7 +986,9 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
                          d_shift_.p, nullptr, a, vcur, d_count, bcap, N_, 1, split, stream_, kWinoStemStages);
         if (dense) launch_wino_in(a, vcur, d_count, bcap, N_, split, stream_, kWinoStages, true);
       }
-      const bool persistent = tower_persistent_ && !dense && stem_wino && wino_tower_supported(stream_);
+      const bool five = use_wino5() && !dense && stem_wino;      // tower layers on the five-pass 64 x 128 form (agz_wino5.hip)
+      const size_t per5 = wino5_weight_floats();
+      const bool persistent = tower_persistent_ && !five && !dense && stem_wino && wino_tower_supported(stream_);
       if (persistent) {
         // the same layers as the loop below, as a table for ONE persistent launch (k_wino_tower)
         const int nl = 2 * tower_;
@@ -1028,11 +1042,21 @@ void Net::forward(const float* d_x32, const int* d_count, int bcap, float* d_pi,
           const int l1 = 2 * blk, l2 = 2 * blk + 1;
           const bool last = blk + 1 == tower_;
           auto layer1 = [&] {
+            if (five) {
+              launch_wino5_gemm(vcur, d_uwino5_.p + per5 * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, nullptr, vnxt,
+                                d_count, bcap, N_, 1, st, part, parts);
+              return;
+            }
             launch_wino_gemm(vcur, usrc + uper * l1, sc + (size_t)l1 * kC, sh + (size_t)l1 * kC, nullptr, dense ? t : nullptr, vnxt,
                              d_count, bcap, N_, 1, split, st, kWinoStages, part, parts);
             if (dense) launch_wino_in(t, vnxt, d_count, bcap, N_, split, st, kWinoStages, true);
           };
           auto layer2 = [&] {
+            if (five) {
+              launch_wino5_gemm(vnxt, d_uwino5_.p + per5 * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, pa, pb,
+                                last ? nullptr : vcur, d_count, bcap, N_, 1, st, part, parts);
+              return;
+            }
             launch_wino_gemm(vnxt, usrc + uper * l2, sc + (size_t)l2 * kC, sh + (size_t)l2 * kC, pa, pb,
                              last ? nullptr : vcur, d_count, bcap, N_, 1, split, st, kWinoStages, part, parts);
             if (dense && !last) launch_wino_in(pb, vcur, d_count, bcap, N_, split, st, kWinoStages, true);
@@ -1226,6 +1250,8 @@ void Net::launch_tower_conv_once(const int* d_count, int bcap) {
     launch_wino4_gemm(d_vimg_.p, d_uwino4_.p, d_scale_.p + kC, d_shift_.p + kC, d_a_.p, d_t_.p, d_vimg2_.p, d_count, bcap, N_, 1, stream_);
     if (!wino4_whole_boards(N_)) launch_wino4_in(d_t_.p, d_vimg2_.p, d_count, bcap, N_, stream_, true);
   }
+  else if (use_wino5())                       // (time_conv: a steady-state layer of the five-pass form)
+    launch_wino5_gemm(d_vimg_.p, d_uwino5_.p, d_scale_.p + kC, d_shift_.p + kC, d_a_.p, d_t_.p, d_vimg2_.p, d_count, bcap, N_, 1, stream_);
   else if (winograd_ && wino_fusable(N_)) {   // a steady-state tower layer: residual in, y and the next V out
     const bool split = precision_ == 2;
     launch_wino_gemm(d_vimg_.p, split ? d_uwino_s_.p : d_uwino_.p, split ? d_scale_s_.p : d_scale_.p + kC, d_shift_.p + kC,

@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace agz {
 
@@ -56,7 +57,14 @@ constexpr int W5VSTAGE = 13 * W5T * 8;       // floats of one stage image of V (
 constexpr int W5IMG = W5T * 9 * W5H;         // floats of the half tile image: 147,456 B
 constexpr int W5PIECES = (W5SV + W5SU) / 256;      // 30 DMA pieces of 1 KB per super-stage
 static_assert(kWinoStages == 64 && kC == 256 && W5PIECES == 30, "stage structure of agz_wino.hip");
-static_assert(3 * W5STAGE <= W5IMG, "the stage ring lies under the tile image");
+#ifndef W5_DIST
+#define W5_DIST 2
+#endif
+constexpr int W5DIST = W5_DIST;              // super-stages a DMA piece is requested ahead of its first read
+constexpr int W5RING = W5DIST + 1;           // stage buffers
+constexpr int W5RN0 = (W5RING * W5STAGE * 4 + 4095) / 4096;      // first residual instruction n whose image bytes lie beyond the ring
+static_assert(W5DIST == 2 || W5DIST == 3, "vmcnt immediates in the kernel");
+static_assert(W5RING * W5STAGE <= W5IMG, "the stage ring lies under the tile image");
 
 // (agz_wino.hip: wino_rows_per_block / wino_whole_boards -- rows of a 64-row tile block that carry tiles)
 __host__ __device__ inline int w5_rows_per_block(int T) {
@@ -69,13 +77,24 @@ __host__ __device__ inline bool w5_whole_boards(int T) { return w5_rows_per_bloc
 // (agz_wino.hip: wino_v_off -- the layout V is stored in)
 __host__ __device__ __forceinline__ int w5_off(int row, int h) { return row * 4 + 2 * ((h + (row >> 4)) & 1); }
 
-template <int MODE>      // bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images
+#ifdef AGZ_TIMING_EXPERIMENTS
+// per workgroup, on the 100 MHz wall clock: [0] hw id | xcc id << 32, [1] start, [2] prologue done (first super-stage published),
+// [3 + 2 p] end of pass p's K loop, [4 + 2 p] end of its fold, [13 + 4 hh + {0, 1, 2, 3}] half hh: residual landed, image
+// written, y stored, next V stored; tools/trace_wino5.py reads it
+__device__ unsigned long long w5_trace[4096][24];
+#define W5_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) w5_trace[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define W5_STAMP(k) do { } while (0)
+#endif
+
+template <int MODE>      // bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images; bit 2: add the residual
 __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     float* __restrict__ vnext, const int* __restrict__ d_count, int N, int T, int relu, int tb0, int tb1) {
   __shared__ __attribute__((aligned(256))) float lds[W5IMG + 64];      // three stage buffers, then the half image + 64 zeros
   __shared__ int ptab[W5T * 9];      // element offset of output point X = k * 64 + row (cout 128 cb of it) in y / res, or -1
+  constexpr bool RES = (MODE & 4) != 0;
   const int P = N * N, TT = T * T;
   const long Mt = (long)(*d_count) * TT;
   const int RPB = w5_rows_per_block(T);
@@ -92,6 +111,15 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
   const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
 
+#ifdef AGZ_TIMING_EXPERIMENTS
+  if (tid == 0 && blockIdx.x < 4096) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    w5_trace[blockIdx.x][0] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
+  W5_STAMP(1);
+#endif
   const float* vsrc = vimg + (long)tb * kWinoStages * W5VSTAGE;
   const float* usrc = uimg + (long)cb * W5UBLOCK;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0];
@@ -100,10 +128,12 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
   // of the pass's five: chunk 5 pass + p % 5 of stage 2 ss + p / 5), else the 1 KB half (p - 10) & 1 of U unit (p - 10) >> 1
   auto dma = [&](int g, int buf, int n) {
     const int p = wave + 4 * n;
-    if (p >= W5PIECES) return;                         // (wave-uniform: waves 2, 3 have seven pieces)
+    if (n == 7 && wave >= 2) return;                   // (wave-uniform: waves 2, 3 have seven pieces)
     const int pass = g >> 5, ss = g & 31;
+    // n < 2: p < 8, a V unit of channel group 0 / 1; n > 2: p >= 12, U; n == 2: p = 8, 9 (V, group 1) for waves 0, 1, else U
+    const bool isv = n < 2 || (n == 2 && wave < 2);
     const float* src;
-    if (p < W5UNITS) {
+    if (isv) {
       const int cg = p >= 5 ? 1 : 0, j = p - 5 * cg;
       src = vsrc + (long)(2 * ss + cg) * W5VSTAGE + (5 * pass + j) * W5VU;
     } else {
@@ -128,6 +158,10 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
   }
 #pragma unroll
   for (int n = 0; n < 8; ++n) dma(1, 1, n);
+  if (W5DIST == 3) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) dma(2, 2, n);
+  }
 
   f32x16 acc[5][2];
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
@@ -141,20 +175,29 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
   auto load = [&](const float* L, int u, int s) {
     ra[s] = *reinterpret_cast<const float2*>(L + aoff + u * W5VU);
     rb0[s] = *reinterpret_cast<const float2*>(L + boff + u * W5UU);
+    __builtin_amdgcn_sched_barrier(0);      // (two ds_read_b64, not one ds_read2st64_b64: 16-lane groups, 2-way conflicts on this layout)
     rb1[s] = *reinterpret_cast<const float2*>(L + boff + u * W5UU + 256);
   };
   // transposed: srcA = U (its rows become D's rows = registers: couts), srcB = V (D's columns = lanes: tile rows)
-  auto mma = [&](int j, int s) {
-    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb0[s].x, ra[s].x, acc[j][0], 0, 0, 0);
-    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb1[s].x, ra[s].x, acc[j][1], 0, 0, 0);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // (zero: a pass's first MFMA of every accumulator takes C = 0 as an inline constant instead of 160 register writes per pass)
+  auto mma = [&](int j, int s, bool zero) {
+    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb0[s].x, ra[s].x, zero ? zero16 : acc[j][0], 0, 0, 0);
+    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb1[s].x, ra[s].x, zero ? zero16 : acc[j][1], 0, 0, 0);
     acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb0[s].y, ra[s].y, acc[j][0], 0, 0, 0);
     acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb1[s].y, ra[s].y, acc[j][1], 0, 0, 0);
   };
 
   // super-stage 0 has landed (this wave's pieces of super-stage 1 may be in flight: eight or seven of them)
-  if (wave < 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  if (W5DIST == 2) {
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  } else {
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  }
   __syncthreads();
+  W5_STAMP(2);
 #pragma unroll
   for (int u = 0; u < LA; ++u) load(lds, u, u);
 
@@ -164,20 +207,23 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
   // front of slot UB = 10 - LA, by when BAR = UB - D0 <= 7 pieces of g + 2 are out for every wave alike: vmcnt(BAR).
   constexpr int UB = W5UNITS - LA, D0 = UB >= 7 ? UB - 7 : 0, BAR = UB - D0;
   int buf = 0;
-  auto sstage = [&](int g) {
-    const int nbuf = buf == 2 ? 0 : buf + 1;
-    const int dbuf = buf == 0 ? 2 : buf - 1;
-    const int g2 = g + 2 >= W5NSS ? g + 2 - W5NSS : g + 2;
+  auto sstage = [&](int g, auto first_c) {
+    constexpr bool first = decltype(first_c)::value;      // the pass's first super-stage
+    const int nbuf = buf == W5RING - 1 ? 0 : buf + 1;
+    const int dbuf = buf == 0 ? W5RING - 1 : buf - 1;      // the buffer super-stage g - 1 was read from
+    const int g2 = g + W5DIST >= W5NSS ? g + W5DIST - W5NSS : g + W5DIST;
     const float* L = lds + buf * W5STAGE;
     const float* Ln = lds + nbuf * W5STAGE;
 #pragma unroll
     for (int u = 0; u < W5UNITS; ++u) {
       const int t = u + LA;
       if (t == W5UNITS) {
-        static_assert(BAR == 7 || BAR == 6 || BAR == 5, "vmcnt immediates below");
-        if (BAR == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else if (BAR == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        // everything this wave owes to super-stage g + 1 has landed; still in flight may be its BAR pieces of the newest
+        // super-stage and, with a distance of three, all eight (waves 2, 3: seven) of the one before
+        static_assert(BAR == 7, "vmcnt immediates below");
+        if (W5DIST == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else if (wave < 2) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         __syncthreads();
       }
       if (t < W5UNITS) load(L, t, t % RING);
@@ -187,27 +233,62 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
         dma(g2, dbuf, u - D0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      mma(u % 5, u % RING);
+      mma(u % 5, u % RING, first && u < 5);
     }
     buf = nbuf;
   };
 
-  // Y[hh][3 i' + j'][q] = elements 2 q, 2 q + 1 (the C/D map's registers = couts) of output point (i', j'), half hh
-  f32x2 Y[2][9][8];
+  // Running outputs: Y[hh][3 i' + j'][q] = elements 2 q, 2 q + 1 (the C/D map's registers = couts) of output point (i', j'),
+  // half hh -- 288 registers beside 160 accumulators.  VALU instructions address the 256 architectural VGPRs only, and the
+  // other half of a lone wave's file (the AGPRs) holds the accumulators, so 96 of the running outputs LIVE in AGPRs, by hand:
+  // half 1's points 0..5 (Y1a), read / fma / written back once per pass.  Left to hipcc the same 96 become "spill slots" and
+  // whatever exceeds them goes to scratch (the first build: 452 bytes, reloads behind vmcnt(0) = behind the DMA in flight).
+  f32x2 Y0[9][8], Y1v[3][8];
+  float Y1a[6][8][2];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
+  for (int k = 0; k < 9; ++k)
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int q = 0; q < 8; ++q) Y0[k][q] = (f32x2){0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) Y[hh][k][q] = (f32x2){0.f, 0.f};
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Y1v[k][q] = (f32x2){0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(Y1a[k][q][0]));
+      asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(Y1a[k][q][1]));
+    }
+  // Residual half-tile -> image by LDS-DMA: instruction i = wave + 4 n (n < 36) fills image bytes 1024 i .. = points 4 i .. 4 i + 3;
+  // lane = (point, unit u) fetches channel group u ^ (X & 15).  Half 0's is on its way before the K loops are through: the image
+  // lies over the stage buffers (4 x 30 KB) and 27 KB beyond them, so instructions n >= W5RN0 (image bytes beyond the ring) go out
+  // behind pass 3 and land during pass 4, the others when pass 4's K loop has ended -- in front of its fold, which covers part of
+  // their flight (the first build waited 6 us per workgroup for a residual requested after the last fold: trace).
+  auto rdma = [&](int n, int hh) {
+    const int i = wave + 4 * n;
+    const int Xp = 4 * i + (lane >> 4), u = lane & 15;
+    const int off = ptab[Xp];
+    const unsigned boff = off >= 0 ? 4u * (unsigned)(off + hh * W5H + 4 * (u ^ (Xp & 15))) : 0u;
+    glds16s(res, boff, lds0 + (unsigned)(i * 256) * 4u);
+  };
   int g = 0;
 #pragma unroll 1
   for (int pass = 0; pass < 5; ++pass) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) acc[j][0] = acc[j][1] = zero16;
+    sstage(g++, std::true_type{});
 #pragma unroll 1
-    for (int ss = 0; ss < W5SSP; ++ss) sstage(g++);
+    for (int ss = 1; ss < W5SSP; ++ss) sstage(g++, std::false_type{});
+    // the fold reads the accumulators through asm, which the hazard recogniser does not see: MFMA D -> VALU read needs 18
+    // wait states after the last MFMA (cdna_hip_programming.md 5.7)
+    __builtin_amdgcn_sched_barrier(0);
+    W5_STAMP(3 + 2 * pass);
+    if (RES && pass == 4) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the wrapped-around DMA of the last two super-stages included)
+      __syncthreads();                                       // every wave has left the K loop: the stage buffers are dead
+#pragma unroll 1
+      for (int n = 0; n < W5RN0; ++n) rdma(n, 0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // fold: t = A^T M[pass][:], Y[i'][:] += A^T[i'][pass] t       A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1]
     const float w0 = pass == 4 ? 0.f : 1.f;
     const float w1 = pass == 1 ? 1.f : pass == 2 ? -1.f : pass == 3 ? 2.f : 0.f;
@@ -219,7 +300,11 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
       for (int q = 0; q < 8; ++q) {
         f32x2 m[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) m[j] = (f32x2){acc[j][hh][2 * q], acc[j][hh][2 * q + 1]};
+        for (int j = 0; j < 5; ++j) {
+          // (read where they are used: left to hipcc, all 160 accumulators are copied to VGPRs in one go ahead of the fold)
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[j][0]) : "a"(acc[j][hh][2 * q]));
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[j][1]) : "a"(acc[j][hh][2 * q + 1]));
+        }
         const f32x2 s12 = m[1] + m[2];
         f32x2 t[3];
         t[0] = (m[0] + s12) + m[3];
@@ -229,12 +314,39 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
         for (int ii = 0; ii < 3; ++ii)
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj) {
-            Y[hh][3 * ii + jj][q] = __builtin_elementwise_fma(wv[ii], t[jj], Y[hh][3 * ii + jj][q]);
-            asm volatile("" : "+v"(Y[hh][3 * ii + jj][q]));      // pin the fold here (agz_wino4.hip: hipcc sinks it otherwise)
+            const int k = 3 * ii + jj;
+            if (hh == 0) {
+              Y0[k][q] = __builtin_elementwise_fma(wv[ii], t[jj], Y0[k][q]);
+              asm volatile("" : "+v"(Y0[k][q]));      // pin the fold here (agz_wino4.hip: hipcc sinks it otherwise)
+            } else if (k >= 6) {
+              Y1v[k - 6][q] = __builtin_elementwise_fma(wv[ii], t[jj], Y1v[k - 6][q]);
+              asm volatile("" : "+v"(Y1v[k - 6][q]));
+            } else {
+              f32x2 yv;
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(yv[0]) : "a"(Y1a[k][q][0]));
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(yv[1]) : "a"(Y1a[k][q][1]));
+              yv = __builtin_elementwise_fma(wv[ii], t[jj], yv);
+              asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(Y1a[k][q][0]) : "v"(yv[0]));
+              asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(Y1a[k][q][1]) : "v"(yv[1]));
+            }
           }
         __builtin_amdgcn_sched_barrier(0);
       }
+    if (RES && pass == 3) {
+#pragma unroll 1
+      for (int n = W5RN0; n < 36; ++n) rdma(n, 0);
+    }
+    W5_STAMP(4 + 2 * pass);
   }
+  // the accumulators are dead: the rest of half 1 joins its first six points in the AGPR half until half 0's epilogue is through
+  float Y1b[3][8][2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(Y1b[k][q][0]) : "v"(Y1v[k][q][0]));
+      asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(Y1b[k][q][1]) : "v"(Y1v[k][q][1]));
+    }
 
   // Everything the epilogue derives from the thread id or its pointer arguments is derived HERE, from opaque copies (hipcc
   // otherwise hoists it above the K loops and parks running outputs in scratch to make room: agz_wino4.hip)
@@ -249,8 +361,10 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
   const int l31_e = lane_e & 31, hi_e = lane_e >> 5;
   float* img = lds;
   const float relu_lo = relu ? 0.f : -3.0e38f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the wrapped-around DMA of the last two super-stages included)
-  __syncthreads();                                       // every wave has left the K loop: the stage buffers are dead
+  if (!RES) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the wrapped-around DMA of the last two super-stages included)
+    __syncthreads();                                     // every wave has left the K loop: the stage buffers are dead
+  }
   if (tid_e < 64) img[W5IMG + tid_e] = 0.f;              // what phase 2 reads for a patch point off the board
 
   // ---- epilogue, once per half hh of the 128 couts (cout block cbe = 2 cb + hh of 64: k_wino_gemm4's).  Half image
@@ -258,8 +372,8 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
 #pragma unroll 1
   for (int hh = 0; hh < 2; ++hh) {
     const int cbe = 2 * cb + hh;
-    if (res_e) {
-      // instruction i = wave + 4 n fills points 4 i .. 4 i + 3: lane = (point, unit u) fetches channel group u ^ (X & 15)
+    if (RES && hh == 1) {
+      // (half 0's residual was requested around the last fold: rdma above)
 #pragma unroll 4
       for (int n = 0; n < 36; ++n) {
         const int i = wave_e + 4 * n;
@@ -285,34 +399,31 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
       for (int qd = 0; qd < 4; ++qd)
         a[qd] = lds0 + 4u * (unsigned)(trow * W5H) + 16u * (unsigned)((8 * wn_e + 2 * qd + hi_e) ^ (trow & 15));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual half-tile (and the affine) have landed
-      if (res_e) __syncthreads();
+      if (RES) __syncthreads();
+      W5_STAMP(13 + 4 * hh);
 #pragma unroll
-      for (int k0 = 0; k0 < 9; k0 += 3) {
-        f32x4 rr[3][4];
+      for (int k = 0; k < 9; ++k) {
+        const unsigned kb = 4u * (unsigned)(k * W5T * W5H);
+        f32x4 rr[4];
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
+        for (int qd = 0; qd < 4; ++qd) {
+          if (RES) rr[qd] = *(const __attribute__((address_space(3))) f32x4*)(size_t)(a[qd] + kb);
+          else rr[qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const unsigned kb = 4u * (unsigned)((k0 + kk) * W5T * W5H);
-            if (res_e) rr[kk][qd] = *(const __attribute__((address_space(3))) f32x4*)(size_t)(a[qd] + kb);
-            else rr[kk][qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int qd = 0; qd < 4; ++qd) {
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int e = 4 * qd + c;
+            v[c] = fmaxf(__builtin_fmaf(Y0[k][e >> 1][e & 1], sc[e], sh[e]) + rr[qd][c], relu_lo);
           }
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const unsigned kb = 4u * (unsigned)((k0 + kk) * W5T * W5H);
-            f32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const int e = 4 * qd + c;
-              v[c] = fmaxf(__builtin_fmaf(Y[0][k0 + kk][e >> 1][e & 1], sc[e], sh[e]) + rr[kk][qd][c], relu_lo);
-            }
-            *(__attribute__((address_space(3))) f32x4*)(size_t)(a[qd] + kb) = v;
-          }
+          *(__attribute__((address_space(3))) f32x4*)(size_t)(a[qd] + kb) = v;
+        }
       }
     }
     __syncthreads();
+    W5_STAMP(14 + 4 * hh);
 
     if (MODE & 1) {
       // phase 1b (k_wino_gemm4's): element = (row, k, 4 channels); 16 consecutive lanes cover the 256 contiguous bytes of one point
@@ -335,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
       }
     }
 
+    W5_STAMP(15 + 4 * hh);
     if (MODE & 2) {
       // phase 2 (k_wino_gemm4's): the next layer's input transform for this half's 64 channels = stages 16 cbe .. 16 cbe + 15 of
       // the next layer's K loop.  Task = (tile row, stage): lane = row, wave w takes stages w, w + 4, w + 8, w + 12.
@@ -408,12 +520,21 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
       }
     }
 
+    W5_STAMP(16 + 4 * hh);
     if (hh == 0) {
-      // the second half runs this same code on its own outputs
+      // the second half runs this same code on its own outputs: out of the AGPR half, into half 0's registers
 #pragma unroll
       for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) Y[0][k][q] = Y[1][k][q];
+        for (int q = 0; q < 8; ++q) {
+          if (k < 6) {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(Y0[k][q][0]) : "a"(Y1a[k][q][0]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(Y0[k][q][1]) : "a"(Y1a[k][q][1]));
+          } else {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(Y0[k][q][0]) : "a"(Y1b[k - 6][q][0]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(Y0[k][q][1]) : "a"(Y1b[k - 6][q][1]));
+          }
+        }
       __syncthreads();      // every wave has left the image: the second half may overwrite it
     }
   }
@@ -479,9 +600,29 @@ void launch_wino5_gemm(const float* vimg, const float* uimg, const float* scale,
   AGZ_REQUIRE((long)(all_blocks + 1) * W5T < (1L << 31) && (long)bcap * N * N * kC * 4 < (1L << 32), AGZ_BAD_ARGUMENT,
               "batch of %d positions at %dx%d: tile index / activation byte offset exceeds 32 bits", bcap, N, N);
 #define W5_LAUNCH(MODE_) hipLaunchKernelGGL((k_wino5_gemm<MODE_>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1)
-  if (y && vnext) W5_LAUNCH(3);
-  else if (vnext) W5_LAUNCH(2);
-  else W5_LAUNCH(1);
+#ifdef AGZ_TIMING_EXPERIMENTS
+  static int traced = 0;
+  if (getenv("AGZ_WINO5_TRACE") && y && vnext && res && ++traced == 3) {      // third steady-state conv2-form launch
+    W5_LAUNCH(7);
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[4096][24];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(w5_trace), sizeof(host));
+    if (FILE* f = fopen(getenv("AGZ_WINO5_TRACE"), "wb")) {
+      fwrite(host, 1, sizeof(host), f);
+      fclose(f);
+    }
+    return;
+  }
+#endif
+  const int mode = (y ? 1 : 0) | (vnext ? 2 : 0) | (res ? 4 : 0);
+  switch (mode) {
+    case 1: W5_LAUNCH(1); break;
+    case 2: W5_LAUNCH(2); break;
+    case 3: W5_LAUNCH(3); break;
+    case 5: W5_LAUNCH(5); break;
+    case 6: W5_LAUNCH(6); break;
+    default: W5_LAUNCH(7); break;
+  }
 #undef W5_LAUNCH
 }
 

@@ -437,7 +437,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32s"],
                     help="tower arithmetic: f32 (default, the BASELINE metric), f16 = the fp16 MFMA path of BASELINE configs[4], "
                          "f32s = the f32 network with Winograd operands split into two f16 halves (fp16 MFMA, f32-grade results)")
-    ap.add_argument("--winograd", type=int, default=1, choices=[0, 1, 2],
+    ap.add_argument("--winograd", type=int, default=1, choices=[0, 1, 2, 3],
                     help="agz_net_set_winograd: 1 = default (F(4x4,3x3) from 13x13 up in exact f32, else F(3x3,3x3)), "
                          "2 = F(3x3,3x3) everywhere, 0 = direct implicit GEMM")
     ap.add_argument("--tower-streams", type=int, default=2, choices=[1, 2, 3, 4],

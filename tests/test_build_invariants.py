@@ -31,10 +31,13 @@ def _scratch_sizes(src):
 
 
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="no hipcc")
-@pytest.mark.parametrize("src,kernel,bound", [("agz_wino4.hip", "k_wino4_gemm", 0), ("agz_wino.hip", "k_wino_gemm4", 16)])
+@pytest.mark.parametrize("src,kernel,bound", [("agz_wino4.hip", "k_wino4_gemm", 0), ("agz_wino.hip", "k_wino_gemm4", 16),
+                                              ("agz_wino5.hip", "k_wino5_gemm", 0)])
 def test_winograd_gemm_kernels_use_no_scratch(src, kernel, bound):
     """bound: bytes of scratch per lane tolerated -- 0 for the F(4x4,3x3) kernel; k_wino_gemm4 has carried two to four
-    dwords of prologue spill (outside its K loop) since round 2, and nothing more may join them"""
+    dwords of prologue spill (outside its K loop) since round 2, and nothing more may join them; the five-pass 64 x 128 form
+    (round 6) holds 160 accumulators + 288 running outputs, 96 of them in AGPRs by hand: its first build, left to hipcc, had
+    452 bytes of scratch in the fold of every pass"""
     sizes = {k: v for k, v in _scratch_sizes(src).items() if kernel in k}
     assert len(sizes) >= 3, sizes
     assert all(v <= bound for v in sizes.values()), {k: v for k, v in sizes.items() if v > bound}
@@ -64,6 +67,7 @@ PRODUCT_NET_KERNELS = {
     "k_wino_tower": {"<false>", "<true>"},
     "k_wino4_gemm": {"<1, 0>", "<2, 0>", "<3, 0>", "<5, 0>", "<6, 0>", "<7, 0>"},
     "k_wino4_in": {"<false, 0>", "<true, 0>"},
+    "k_wino5_gemm": {"<1>", "<2>", "<3>", "<5>", "<6>", "<7>"},
     "k_conv3x3_f16_q": {"<0, false>", "<1, false>"},
     "k_conv3x3_f16_w2": {"<0, 0, true, 7, false, false, 0>", "<0, 1, true, 7, false, false, 0>",
                          "<0, 2, true, 7, false, false, 0>", "<0, 2, false, 7, false, false, 0>"},

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../alphago.jl_amd/csrc"
 make -s
 T=/tmp/agz_timing_build; mkdir -p $T
 OBJS=""
-for f in agz_nn agz_wino agz_wino4 agz_conv16 agz_engine agz_capi agz_comm agz_train; do
+for f in agz_nn agz_wino agz_wino4 agz_wino5 agz_conv16 agz_engine agz_capi agz_comm agz_train; do
   if [[ " agz_wino4 ${ALSO:-} " == *" $f "* ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DAGZ_TIMING_EXPERIMENTS ${EXTRA:-} -c $f.hip -o $T/$f.o
     OBJS="$OBJS $T/$f.o"
