@@ -398,28 +398,46 @@ def self_launch(n, single_device):
             print(f"bench.py: --gpus {n} but {have} GPU(s) visible (one rank per GPU; --single-device-test puts every "
                   f"rank on cuda:0 for a rehearsal)", file=sys.stderr)
             return 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   AGZ_BENCH_SELF_LAUNCHED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc, deadline = 0, None
-    while any(p.poll() is None for p in procs):
-        for p in procs:
-            if p.poll() not in (None, 0) and deadline is None:
-                rc, deadline = p.returncode, time.time() + 30.0        # one rank died: the others get 30 s to follow
-        if deadline is not None and time.time() > deadline:
-            for p in procs:                                            # (exactly the processes started above)
-                if p.poll() is None:
-                    p.kill()
-        time.sleep(0.2)
-    return rc or max((abs(p.returncode) for p in procs), default=0)
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return port
+
+    # The port is picked by bind-then-close: another process can take it before rank 0's store binds it.  A run
+    # whose ranks all die within 20 s without a line is started again on a new port, up to three times.
+    rc = 1
+    for attempt in range(3):
+        port = free_port()
+        t_start = time.time()
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       AGZ_BENCH_SELF_LAUNCHED="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else sys.stderr))
+        failed, deadline = False, None
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                if p.poll() not in (None, 0) and deadline is None:
+                    failed, deadline = True, time.time() + 30.0        # one rank died: the others get 30 s to follow
+            if deadline is not None and time.time() > deadline:
+                for p in procs:                                        # (exactly the processes started above)
+                    if p.poll() is None:
+                        p.kill()
+            time.sleep(0.2)
+        codes = [p.returncode for p in procs]
+        if all(c == 0 for c in codes):
+            return 0
+        # a child killed by a signal reports a negative code: the launcher's own status is 1 for any failure
+        rc = 1
+        if not (failed and time.time() - t_start < 20.0):
+            break                                                      # not a rendezvous failure: do not run the bench twice
+        print(f"bench.py: ranks exited with {codes} after {time.time() - t_start:.0f} s (port {port}); retrying on a new port",
+              file=sys.stderr)
+    return rc
 
 
 def main():

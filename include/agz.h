@@ -140,8 +140,11 @@ agz_status agz_net_time_conv(agz_engine* e, int32_t B, int32_t iters, float* ms_
 
 /* tower-convolution algorithm: 1 (default) = Winograd on the f32 MFMA -- F(3x3,3x3), and for boards of 13x13 and
  * larger in the exact-f32 arithmetic F(4x4,3x3) (a quarter fewer multiplies at 19x19); 2 = Winograd F(3x3,3x3) on every
- * board size (comparison runs); 0 = direct implicit GEMM on the f32 MFMA.  All are f32 end to end; they differ by
- * rounding only (each within 1e-4 of the float64 network: tests/test_gpu_nn.py, tests/test_gpu_configs.py). */
+ * board size (comparison runs); 0 = direct implicit GEMM on the f32 MFMA; 3 = 1 with the tower layers of boards whose tile
+ * blocks hold whole boards (N <= 12) on the five-pass 64-tile x 128-cout form of F(3x3,3x3) (agz_wino5.hip: 25 % fewer
+ * operand bytes per flop, the same layer time within 0.5 % on the 9x9 headline -- opt-in, tests/test_gpu_wino5.py).  All
+ * are f32 end to end; they differ by rounding only (each within 1e-4 of the float64 network: tests/test_gpu_nn.py,
+ * tests/test_gpu_configs.py). */
 agz_status agz_net_set_winograd(agz_engine* e, int32_t on);
 /* the f32 Winograd tower as one launch per layer (0, default) or as ONE persistent launch over all its layers (1: used
  * wherever it applies -- board sizes whose tile blocks hold whole boards (N <= 12), a 256-CU device).  The same device

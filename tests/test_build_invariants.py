@@ -62,11 +62,11 @@ LIB = os.path.join(ROOT, "alphago.jl_amd", "libagz.so")
 
 # every tower / network kernel instantiation the product library may hold: the list is the review
 PRODUCT_NET_KERNELS = {
-    "k_wino_gemm4": {"<1, 0, false, 64>", "<1, 0, true, 64>", "<2, 0, false, 64>", "<2, 0, true, 64>", "<3, 0, false, 64>",
-                     "<3, 0, true, 64>", "<1, 0, false, 8>", "<1, 0, true, 8>", "<3, 0, false, 8>", "<3, 0, true, 8>"},
+    "k_wino_gemm4": {"<1, false, 64>", "<1, true, 64>", "<2, false, 64>", "<2, true, 64>", "<3, false, 64>",
+                     "<3, true, 64>", "<1, false, 8>", "<1, true, 8>", "<3, false, 8>", "<3, true, 8>"},
     "k_wino_tower": {"<false>", "<true>"},
-    "k_wino4_gemm": {"<1, 0>", "<2, 0>", "<3, 0>", "<5, 0>", "<6, 0>", "<7, 0>"},
-    "k_wino4_in": {"<false, 0>", "<true, 0>"},
+    "k_wino4_gemm": {"<1>", "<2>", "<3>", "<5>", "<6>", "<7>"},
+    "k_wino4_in": {"<false>", "<true>"},
     "k_wino5_gemm": {"<1>", "<2>", "<3>", "<5>", "<6>", "<7>"},
     "k_conv3x3_f16_q": {"<0, false>", "<1, false>"},
     "k_conv3x3_f16_w2": {"<0, 0, true, 7, false, false, 0>", "<0, 1, true, 7, false, false, 0>",

@@ -143,7 +143,7 @@ __device__ __forceinline__ void bt6(V x0, V x1, V x2, V x3, V x4, V x5, V* r) {
 // Those are at most T + 1 <= 8 rows at either end of a block, so the grid is again 2 x tile blocks, but a workgroup
 // takes EIGHT rows (0..7 or 56..63) x 32 lanes (16 channel groups): 4 passes of 64 channels instead of 16 of 16 over
 // 32 mostly idle tiles (the first form of this kernel: 0.30 ms per layer, a tenth of it); whole 128-byte lines are written.
-template <bool FIXUP>
+template <bool FIXUP, int X = 0>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, float* __restrict__ vimg,
                                                   const int* __restrict__ d_count, int N, int T, int tb0, int tb1) {
   constexpr int TPB = FIXUP ? 8 : 32;            // tile rows per workgroup
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
     f32x2 d[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) {
+      if (X == 2) { d[q] = (f32x2){(float)off[q], (float)ch}; continue; }
       // every lane loads (an off-board point reads x[ch]: in bounds, discarded): 36 loads in flight, no branch per load
       const f32x2 got = *reinterpret_cast<const f32x2*>(x + (off[q] >= 0 ? off[q] : 0) + ch);
       d[q] = off[q] >= 0 ? got : (f32x2){0.f, 0.f};
@@ -228,9 +229,10 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, f
       int stage, unit;
       w4_slot(pl / 6, pl % 6, pass * GP + s4, stage, unit);
       f32x4* gp = reinterpret_cast<f32x4*>(gdst + (long)stage * W4HALF + unit * W4UNIT + cl * 4);
+      if (X == 1 && v[0] != 12345.f) continue;
       // FIXUP: 128-byte pieces 1 KB apart -- as plain stores they merge in L2 and leave with the kernel's write-back
-      // (0.155 -> 0.12 ms per layer at 2048 boards of 19x19 against the streaming form)
-      if (FIXUP) { *gp = v; continue; }
+      // (0.155 -> 0.12 ms per layer at 2048 boards of 19x19 against the streaming form, which X == 3 keeps for timing)
+      if (FIXUP && X != 3) { *gp = v; continue; }
       __builtin_nontemporal_store(v, gp);
     }
   }
@@ -251,10 +253,19 @@ __device__ __forceinline__ void w4_fold_row(const f32x2 m0, const f32x2 m1, cons
   t[3] = (d12 + 8.f * d34) + m5;
 }
 
+#ifdef AGZ_TIMING_EXPERIMENTS
+// per workgroup, on the 100 MHz wall clock: [0] hw id | xcc id << 32, [1] start, [2] prologue done (first stage published),
+// [3..8] end of pass 0..5 (K loop + fold), [9 + 4 hh + {0, 1, 2, 3}] half hh: residual landed, image written, y stored,
+// next V stored; tools/trace_wino4.py reads it
+__device__ unsigned long long w4_trace[8192][20];
+#define W4_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) w4_trace[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define W4_STAMP(k) do { } while (0)
+#endif
 
 // MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images; bit 2: add the residual.
-// (The timing variants of round 4 -- results WRONG -- and the wall-clock stamps: tools/experiments/agz_wino4_variants.hip,
-// which tools/build_timing_lib.sh compiles in place of this file.)
+// X (timing experiments, -DAGZ_TIMING_EXPERIMENTS only; results WRONG): 1 = K loops and folds only; 2 = no phase 2;
+// 3 = phase 2 without its global stores; 4 = no DMA after the prologue; 5 = no MFMA; 6 = no folds; 7 = no LDS operand reads; 8 = neither DMA nor operand reads in the K loop; 9 = 8 without the stage barrier
 //
 // Code size is a design constraint here: the first form of this kernel (each pass's first stage and the two tail stages
 // peeled, the epilogue's halves as two copies: 65 KB of code) ran its straight-line sections -- folds, epilogue -- at
@@ -263,7 +274,7 @@ __device__ __forceinline__ void w4_fold_row(const f32x2 m0, const f32x2 m1, cons
 // body (accumulators zeroed in front of a pass, the DMA of the last two stages wraps around to stages 0 and 1 and is
 // thrown away), passes C and D are one loop, and the epilogue's second half runs the first half's code after moving the
 // upper register quads down.
-template <int MODE>
+template <int MODE, int X>
 __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
@@ -292,6 +303,15 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
   const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
 
+#ifdef AGZ_TIMING_EXPERIMENTS
+  if (tid == 0 && blockIdx.x < 8192) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    w4_trace[blockIdx.x][0] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
+  W4_STAMP(1);
+#endif
   const float* asrc = vimg + (long)tb * W4BLOCK;
   const float* bsrc = uimg + (long)cb * W4BLOCK;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0];
@@ -346,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
 
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 has landed (stage 1's 12 pieces may be in flight)
   __syncthreads();
+  W4_STAMP(2);
 #pragma unroll
   for (int u = 0; u < RING; ++u) ra[u] = rb[u] = make_float2(1.f, 0.5f);
 #pragma unroll
@@ -368,11 +389,13 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
       if (t == W4UNITS) {
         // everything this wave owes to stage st + 1 has landed (its 12 pieces of stage st + 2, all issued by now, may be
         // in flight); hipcc adds lgkmcnt(0) in front of the barrier: all reads of stage st are back
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        __syncthreads();
+        if (X != 4 && X != 8 && X != 9) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (X != 9) __syncthreads();
       }
-      if (t < W4UNITS) load(L, t, ra[t % RING], rb[t % RING]);
-      else load(Ln, t - W4UNITS, ra[t % RING], rb[t % RING]);
+      if (X != 7 && X != 8 && X != 9) {
+        if (t < W4UNITS) load(L, t, ra[t % RING], rb[t % RING]);
+        else load(Ln, t - W4UNITS, ra[t % RING], rb[t % RING]);
+      }
       // (one unit's reads at a time: left alone, hipcc merges the reads of two units into ds_read2st64_b64, which the LDS
       // serves in 16-lane groups over 32 banks -- 2-way conflicts on this layout, 16 cycles for what two ds_read_b64 do
       // in 4; SQ_LDS_BANK_CONFLICT 0.37 of the LDS cycles, -2.8 % per layer without them, same box)
@@ -380,10 +403,10 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
       constexpr int D0 = 6;
       if (u >= D0 && u < D0 + 12) {
         __builtin_amdgcn_sched_barrier(0);
-        dma(st2, dbuf, u - D0);
+        if (X != 4 && X != 8 && X != 9) dma(st2, dbuf, u - D0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      mma(u % PL, ra[u % RING], rb[u % RING]);
+      if (X != 5) mma(u % PL, ra[u % RING], rb[u % RING]);
     }
     buf = nbuf;
   };
@@ -404,31 +427,50 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
     for (int p = 0; p < 6; ++p) acc[p] = zero16;
 #pragma unroll 1
     for (int st = 0; st < 16; ++st) stage(16 * pass + st);
-    //            i =  0   1   2   3   4   5
-    // A^T[0][i]      1   1   1   1   1   0
-    // A^T[1][i]      0   1  -1   2  -2   0
-    // A^T[2][i]      0   1   1   4   4   0
-    // A^T[3][i]      0   1  -1   8  -8   1
-    const float sgn = (pass & 1) ? 1.f : -1.f, mid = (pass >= 1 && pass <= 4) ? 1.f : 0.f, big = pass >= 3 ? 1.f : 0.f;
-    const float w0 = pass == 5 ? 0.f : 1.f;
-    const float w1 = mid * sgn * (1.f + big);              // 0 1 -1 2 -2 0
-    const float w2 = mid * (1.f + 3.f * big);              // 0 1 1 4 4 0
-    const float w3 = pass == 5 ? 1.f : mid * sgn * (1.f + 7.f * big);      // 0 1 -1 8 -8 1
-    const f32x2 wv[4] = {{w0, w0}, {w1, w1}, {w2, w2}, {w3, w3}};
+    if (X != 6) {
+      //            i =  0   1   2   3   4   5
+      // A^T[0][i]      1   1   1   1   1   0
+      // A^T[1][i]      0   1  -1   2  -2   0
+      // A^T[2][i]      0   1   1   4   4   0
+      // A^T[3][i]      0   1  -1   8  -8   1
+      const float sgn = (pass & 1) ? 1.f : -1.f, mid = (pass >= 1 && pass <= 4) ? 1.f : 0.f, big = pass >= 3 ? 1.f : 0.f;
+      const float w0 = pass == 5 ? 0.f : 1.f;
+      const float w1 = mid * sgn * (1.f + big);              // 0 1 -1 2 -2 0
+      const float w2 = mid * (1.f + 3.f * big);              // 0 1 1 4 4 0
+      const float w3 = pass == 5 ? 1.f : mid * sgn * (1.f + 7.f * big);      // 0 1 -1 8 -8 1
+      const f32x2 wv[4] = {{w0, w0}, {w1, w1}, {w2, w2}, {w3, w3}};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      f32x2 t[4];
-      w4_fold_row(pair_of(0, q), pair_of(1, q), pair_of(2, q), pair_of(3, q), pair_of(4, q), pair_of(5, q), t);
+      for (int q = 0; q < 8; ++q) {
+        f32x2 t[4];
+        w4_fold_row(pair_of(0, q), pair_of(1, q), pair_of(2, q), pair_of(3, q), pair_of(4, q), pair_of(5, q), t);
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
+        for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          Y[4 * ii + jj][q] = __builtin_elementwise_fma(wv[ii], t[jj], Y[4 * ii + jj][q]);
-          // pin the fold here: hipcc otherwise sinks it towards the epilogue and keeps every pass's accumulators alive
-          asm volatile("" : "+v"(Y[4 * ii + jj][q]));
-        }
-      __builtin_amdgcn_sched_barrier(0);       // a pair at a time: interleaved, their temporaries crowd out the outputs
+          for (int jj = 0; jj < 4; ++jj) {
+            Y[4 * ii + jj][q] = __builtin_elementwise_fma(wv[ii], t[jj], Y[4 * ii + jj][q]);
+            // pin the fold here: hipcc otherwise sinks it towards the epilogue and keeps every pass's accumulators alive
+            asm volatile("" : "+v"(Y[4 * ii + jj][q]));
+          }
+        __builtin_amdgcn_sched_barrier(0);       // a pair at a time: interleaved, their temporaries crowd out the outputs
+      }
     }
+    W4_STAMP(3 + pass);
+  }
+  if (X == 6) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) Y[k][q] = pair_of(k % 6, q);
+  }
+  if (X == 1) {
+    float keep = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) keep += Y[k][q][0] + Y[k][q][1];
+    if (keep == 123.456f) y[0] = keep;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
   }
 
   // Everything the epilogue derives from the thread id or from its pointer arguments is derived HERE, from opaque copies:
@@ -513,6 +555,7 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
       }
     }
     __syncthreads();
+    W4_STAMP(10 + 4 * hh);
 
     if (MODE & 1) {
       // image -> y_e: 8 consecutive lanes cover the 128 contiguous bytes of one output point's half; thread tid_e handles
@@ -534,7 +577,9 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
           if (offs[j] >= 0) *reinterpret_cast<f32x4*>(y_e + offs[j] + cg4) = v[j];
       }
     }
-    if (MODE & 2) {
+
+    W4_STAMP(11 + 4 * hh);
+    if ((MODE & 2) && X != 2) {
       // ---- the next layer's input transform for this half's 32 channels = 8 channel groups (groups cb * 16 + hh * 8 + g
       // of the next layer's 64).  Task = (tile row, group): lane_e = row, wave_e w takes groups w and w + 4.
       const int row = lane_e;
@@ -603,10 +648,15 @@ __global__ __launch_bounds__(256, 1) void k_wino4_gemm(
             const f32x2 p0 = vv[i * 6 + j][0], p1 = vv[i * 6 + j][1];
             const f32x4 v4 = {p0[0], p0[1], p1[0], p1[1]};      // (already in the row's pair order: see the reads above)
             f32x4* gp = reinterpret_cast<f32x4*>(gbase + o);
+            if (X == 3) {
+              if (v4[0] + v4[3] == 123.456f) *gp = v4;
+              continue;
+            }
             if (emit) __builtin_nontemporal_store(v4, gp);
           }
       }
     }
+    W4_STAMP(12 + 4 * hh);
     if (hh == 0) {
       // the second half runs this same code: its registers (8..15 of every tuple, and of the affine) move down
 #pragma unroll
@@ -716,6 +766,13 @@ void launch_wino4_in(const float* x, float* vimg, const int* d_count, int bcap, 
   wino4_check(bcap, N);
   if (fixup) {
     AGZ_REQUIRE(!w4_whole_boards(T) && T + 1 <= 8, AGZ_BAD_ARGUMENT, "fix-up transform: dense tile blocks, at most 8 rows at a block's ends");
+#ifdef AGZ_FIXUP_EXPERIMENTS
+    static const int fx = getenv("AGZ_WINO4_FX") ? atoi(getenv("AGZ_WINO4_FX")) : 0;      // 1 no stores, 2 no loads, 3 streaming stores, 4 no kernel
+    if (fx == 4) return;
+    if (fx == 1) { hipLaunchKernelGGL((k_wino4_in<true, 1>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1); return; }
+    if (fx == 3) { hipLaunchKernelGGL((k_wino4_in<true, 3>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1); return; }
+    if (fx == 2) { hipLaunchKernelGGL((k_wino4_in<true, 2>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1); return; }
+#endif
     hipLaunchKernelGGL((k_wino4_in<true>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1);
   } else {
     hipLaunchKernelGGL((k_wino4_in<false>), dim3(2 * (tb1 - tb0)), dim3(256), 0, s, x, vimg, d_count, N, T, tb0, tb1);
@@ -738,15 +795,44 @@ void launch_wino4_gemm(const float* vimg, const float* uimg, const float* scale,
   // kernel's last argument
   AGZ_REQUIRE(!ypart || (w4_paired(T) && y && !res && tb1 < (1 << 30)), AGZ_BAD_ARGUMENT, "F(4x4,3x3) GEMM: partial y needs paired packing and no residual");
   const int tb1y = tb1 | (ypart ? 1 << 30 : 0);
-#define W4_LAUNCH(MODE_) hipLaunchKernelGGL((k_wino4_gemm<MODE_>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1y)
+#define W4_LAUNCH(MODE_, X_) hipLaunchKernelGGL((k_wino4_gemm<MODE_, X_>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1y)
+#ifdef AGZ_TIMING_EXPERIMENTS
+  static const int xp = getenv("AGZ_WINO4_X") ? atoi(getenv("AGZ_WINO4_X")) : 0;
+  static int traced = 0;
+  if (getenv("AGZ_WINO4_TRACE") && y && vnext && res && ++traced == 3) {      // third steady-state conv2-form launch
+    W4_LAUNCH(7, 0);
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[8192][20];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(w4_trace), sizeof(host));
+    if (FILE* f = fopen(getenv("AGZ_WINO4_TRACE"), "wb")) {
+      fwrite(host, 1, sizeof(host), f);
+      fclose(f);
+    }
+    return;
+  }
+  if (xp && y && vnext && res) {
+    switch (xp) {
+      case 1: W4_LAUNCH(7, 1); return;
+      case 2: W4_LAUNCH(7, 2); return;
+      case 3: W4_LAUNCH(7, 3); return;
+      case 4: W4_LAUNCH(7, 4); return;
+      case 5: W4_LAUNCH(7, 5); return;
+      case 6: W4_LAUNCH(7, 6); return;
+      case 7: W4_LAUNCH(7, 7); return;
+      case 8: W4_LAUNCH(7, 8); return;
+      case 9: W4_LAUNCH(7, 9); return;
+      default: break;
+    }
+  }
+#endif
   const int mode = (y ? 1 : 0) | (vnext ? 2 : 0) | (res ? 4 : 0);
   switch (mode) {
-    case 1: W4_LAUNCH(1); break;
-    case 2: W4_LAUNCH(2); break;
-    case 3: W4_LAUNCH(3); break;
-    case 5: W4_LAUNCH(5); break;
-    case 6: W4_LAUNCH(6); break;
-    default: W4_LAUNCH(7); break;
+    case 1: W4_LAUNCH(1, 0); break;
+    case 2: W4_LAUNCH(2, 0); break;
+    case 3: W4_LAUNCH(3, 0); break;
+    case 5: W4_LAUNCH(5, 0); break;
+    case 6: W4_LAUNCH(6, 0); break;
+    default: W4_LAUNCH(7, 0); break;
   }
 #undef W4_LAUNCH
 }

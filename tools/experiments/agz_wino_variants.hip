@@ -264,15 +264,23 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
 // one channel group for all its elements -- the epilogue is VALU-issue bound (a lone wave per SIMD), address
 // arithmetic per access is what it can least afford.
 constexpr int IMG_FLOATS = WT * 9 * WC;          // 147,456 B
+#ifdef AGZ_TIMING_EXPERIMENTS
+// per workgroup: {hw id | xcc id << 32, start, K loop done, phase 1 done, phase 1b done, end} on the 100 MHz wall clock
+__device__ unsigned long long g4_trace[16384][8];
+#define G4_STAMP(k) do { if (tid == 0 && blockIdx.x < 16384) g4_trace[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define G4_STAMP(k) do { } while (0)
+#endif
 
 // MODE bit 0: write y (affine, residual, ReLU applied); bit 1: emit the next layer's V stage images.
-// (The timing variants of rounds 2-5 -- parts of this function compiled out or redirected, results WRONG -- and the wall-clock
-// stamps live in tools/experiments/agz_wino_variants.hip, which tools/build_timing_lib.sh compiles in place of this file.)
+// X: timing experiments, instantiated only under -DAGZ_TIMING_EXPERIMENTS (results are WRONG for X != 0):
+//   1 = K loop only; 2 = no epilogue 2; 3 = epilogue 2 without its global stores; 4 = no DMA after the prologue;
+//   5 = no MFMA; 6 = no LDS operand reads; 7..10, 16..18 = projections (see the K loop); 13 / 14 / 15 = every stage's DMA (of both operands / U / V) from the same two (L2-resident) stage images
 // NS: stages of the K loop (input channels / 4): 64, or 8 for the stem
 // COH: every LDS-DMA load carries sc1 (served by L2, not by this CU's L1): the persistent tower kernel below reads what
 // other workgroups of its XCD wrote earlier in the same launch.  Costs nothing (same-box A/B +-0).
 // One workgroup's work: tile block tb x cout block cb of one layer.  lds / ptab: the workgroup's shared memory.
-template <bool SPLIT, int NS, bool COH>
+template <int X, bool SPLIT, int NS, bool COH>
 __device__ __forceinline__ void wino_wg(
     float* __restrict__ lds, int* __restrict__ ptab, const float* __restrict__ vimg, const float* __restrict__ uimg,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
@@ -284,7 +292,18 @@ __device__ __forceinline__ void wino_wg(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
-  const float* asrc = vimg + (long)tb * NS * A_STAGE;
+#ifdef AGZ_TIMING_EXPERIMENTS
+  if (tid == 0 && blockIdx.x < 16384) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g4_trace[blockIdx.x][0] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
+  G4_STAMP(1);
+#endif
+  // (timing 16 / 17 / 18: what a quad-private, cache-resident V scratch would buy -- 64 slabs instead of one per tile
+  // block: 17 the V loads come from slab tb % 64, 16 the V stores go there, 18 both)
+  const float* asrc = vimg + (long)((X == 17 || X == 18) ? (tb & 63) : tb) * NS * A_STAGE;
   const float* bsrc = uimg + (long)cb * NS * B_STAGE;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[0];
 
@@ -293,7 +312,9 @@ __device__ __forceinline__ void wino_wg(
   // address arithmetic in front of every piece cost 8 % of the K loop (2.10 -> 1.95 ms per layer)
   auto dma = [&](int st, int buf, int j) {
     const int c = 13 * wave + j;
-    const float* g = wave < 2 ? asrc + (long)st * A_STAGE + c * 256 : bsrc + (long)st * B_STAGE + (c - 26) * 256;
+    // (timing: every stage from the same two L2-resident stage images: 13 both operands, 14 only U, 15 only V)
+    const int sa = (X == 13 || X == 15) ? (st & 1) : st, sb = (X == 13 || X == 14) ? (st & 1) : st;
+    const float* g = wave < 2 ? asrc + (long)sa * A_STAGE + c * 256 : bsrc + (long)sb * B_STAGE + (c - 26) * 256;
     if constexpr (COH) glds16s_l2(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
     else glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
   };
@@ -325,6 +346,12 @@ __device__ __forceinline__ void wino_wg(
   // (not zeroed: the first MFMA of every plane takes C = 0 as an inline constant -- 400 register writes per lane that
   // sat, exposed, between the workgroup's start and its first MFMA)
   f32x16 acc[WXI];
+  if (X == 5) {      // (the no-MFMA timing variant never writes them)
+#pragma unroll
+    for (int i = 0; i < WXI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  }
 
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
   const int brot = wino_rot(brow);
@@ -345,6 +372,7 @@ __device__ __forceinline__ void wino_wg(
       a = *reinterpret_cast<const f32x4*>(L + asoff[xi & 1] + (xi >> 1) * (WT * 8));
       b = *reinterpret_cast<const float2*>(L + bsoff[xi & 1] + (xi >> 1) * (WC * 8));
     } else {
+      if (X == 6) { a = make_float2(1.f, (float)lane); b = make_float2(2.f, (float)xi); return; }
       a = *reinterpret_cast<const float2*>(L + aoff[xi & 1] + (xi >> 1) * (WT * 8));
       b = *reinterpret_cast<const float2*>(L + boff[xi & 1] + (xi >> 1) * (WC * 8));
     }
@@ -393,15 +421,41 @@ __device__ __forceinline__ void wino_wg(
     }
   };
 
-  constexpr int PW = 13;      // DMA pieces per wave and stage
-  auto wait_stage = [&]() { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); };
+  // (projection experiments, DESIGN 4e: X = 8 moves 11 instead of 13 pieces per wave and stage -- the DMA volume of a
+  // half-transformed A operand; X = 9 adds the 50 packed operations per stage its second pass would cost the wave;
+  // X = 10 stores 15 of the 25 planes in phase 2 after one transform pass; X = 7 all three.  Results are WRONG.)
+  constexpr int PW = (X == 7 || X == 8) ? 11 : 13;
+  auto wait_stage = [&]() {
+    if constexpr (PW == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  };
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t dum0 = {1.f, 2.f}, dum1 = {3.f, 4.f}, dumc = {0.5f, 0.25f};
+#ifdef AGZ_X_PROLOGUE_STAMP
+  G4_STAMP(6);      // (this build only: slot 6 = set-up done, slot 7 = first stage landed and published)
+#endif
   wait_stage();
   __syncthreads();
+#ifdef AGZ_X_PROLOGUE_STAMP
+  G4_STAMP(7);
+#endif
 #pragma unroll
   for (int k = 0; k < LA; ++k) load(lds, k, ra[k], rb[k]);
 
   // One stage.  MORE: stage st+2 exists and is fetched during this stage; NEXT: stage st+1 exists.  Both are
   // compile-time so that the 62 full stages run a branch-free body (the two tail stages are separate code).
+  // Residual prefetch.  The tile image of the epilogue lies over the three stage buffers; the buffer of stage NS-3 is
+  // dead during stage NS-2 and that of stage NS-2 during stage NS-1, when the K loop has no pieces of its own left to
+  // fetch: the residual's pieces for those two thirds of the image (instruction i = wave + 4 n fills image bytes
+  // 1024 i ..: n 13..25 lie in buffer 1, n 26..35 in buffer 2, NS % 3 == 1 makes those the dead ones) go out in the DMA
+  // slots of the last two stages instead of behind the loop, where the inverse transform (1.5 us) is too short to cover
+  // 144 KB arriving from HBM at 16 B/clk/CU (3.9 us).  n 0..12 (buffer 0, the last stage's) follow behind the loop.
+  static_assert(NS % 3 == 1 || NS == kWinoStemStages, "residual prefetch assumes the last stage is read from buffer 0");
+#ifdef AGZ_X_RESPF         // measured: phase 1 -2.9 us, phase 2 +2.1 us (the epilogues stay in lockstep), layer +-0
+  constexpr bool RESPF = NS % 3 == 1;
+#else
+  constexpr bool RESPF = false;
+#endif
   auto rdma = [&](int n) {
     // instruction i fills points 4i .. 4i+3: lane = (point, unit u) fetches channel group u ^ (X & 15)
     const int i = wave + 4 * n;
@@ -425,7 +479,9 @@ __device__ __forceinline__ void wino_wg(
       if (t == WXI && next) {
         // everything this wave owes to stage st+1 has landed (its share of stage st+2, all 13 pieces issued by
         // now, may still be in flight); hipcc adds lgkmcnt(0) in front of the barrier: all reads of stage st are back
-        if (more) wait_stage();
+        // (stage NS-2 with a residual: the 13 youngest are this stage's residual pieces)
+        if (more && X != 4) wait_stage();
+        else if (!more && RESPF && res && X != 4) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
@@ -436,11 +492,21 @@ __device__ __forceinline__ void wino_wg(
       constexpr int D0 = SPLIT ? 0 : 6;      // (f32, same-box: D0 = 3 and 9 the same, D0 = 0 +1 % per forward)
       if (more && k >= D0 && k < D0 + PW) {
         __builtin_amdgcn_sched_barrier(0);
-        dma(st + 2, dbuf, k - D0);
+        if (X != 4) dma(st + 2, dbuf, k - D0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (first) mma0(k, ra[k % RING], rb[k % RING]);
-      else mma(k, ra[k % RING], rb[k % RING]);
+      if (X == 7 || X == 9) {
+        asm volatile("v_pk_fma_f32 %0, %0, %2, %0\n\tv_pk_fma_f32 %1, %1, %2, %1" : "+v"(dum0), "+v"(dum1) : "v"(dumc));
+      }
+      if (!more && RESPF && k >= D0 && k < D0 + (next ? 13 : 10)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (res) rdma((next ? 13 : 26) + k - D0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (X != 5) {
+        if (first) mma0(k, ra[k % RING], rb[k % RING]);
+        else mma(k, ra[k % RING], rb[k % RING]);
+      }
     }
     buf = nbuf;
   };
@@ -456,6 +522,14 @@ __device__ __forceinline__ void wino_wg(
   asm volatile("s_nop 15\n\ts_nop 15"
                : "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[18]),
                  "+v"(acc[19]), "+v"(acc[23]), "+v"(acc[24]));
+  if (X == 1) {
+    float keep = 0.f;
+#pragma unroll
+    for (int k = 0; k < WXI; ++k) keep += acc[k][0] + acc[k][15];
+    if (keep == 123.456f) y[0] = keep;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // residual pieces may still be landing in LDS
+    return;
+  }
 
   // ---- epilogue.  The stage buffers are dead once every wave has left the K loop; they become the tile image
   // img (layout above).  Phases, each with every memory operation of the phase in flight at once -- a lone wave
@@ -465,6 +539,7 @@ __device__ __forceinline__ void wino_wg(
   //   1b  img -> y: 256-byte runs per output point, 16 B per lane; only where y is wanted (MODE & 1)
   //   2   next layer's input transform V = B^T d B from img -> HBM stage images   (MODE & 2)
   __syncthreads();
+  G4_STAMP(2);
   float* img = lds;
   static_assert(IMG_FLOATS + WC <= 3 * STAGE, "tile image (+ the block of zeros phase 2 reads for off-board points) exceeds the stage buffers");
   if (tid < WC) img[IMG_FLOATS + tid] = 0.f;        // (published by the barrier behind phase 1)
@@ -472,7 +547,7 @@ __device__ __forceinline__ void wino_wg(
   if (res) {
     static_assert(WT * 9 / 4 == 4 * 36, "36 residual pieces per wave");
 #pragma unroll
-    for (int n = 0; n < 36; ++n) rdma(n);
+    for (int n = 0; n < (RESPF ? 13 : 36); ++n) rdma(n);
   }
   {
     // phase 1.  C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -500,13 +575,21 @@ __device__ __forceinline__ void wino_wg(
         o[i * 3 + 2] = ((tmp[i][1] + tmp[i][2]) + 4.f * tmp[i][3]) + tmp[i][4];
       }
     }
-    // (hipcc sinks this transform below the residual's wait and barrier -- it is register arithmetic, nothing orders it against
-    // them; pinning it there and requesting two thirds of the residual from the last two K stages was measured: phase 1 -2.9 us,
-    // phase 2 +2.1 us, layer +-0, HISTORY.md 4e; the source of that build is tools/experiments/agz_wino_variants.hip)
+    // hipcc would otherwise sink the whole transform below the wait and the barrier (it is register arithmetic, nothing
+    // orders it against them) and the wave would sit out the residual's flight before starting on it
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if (RESPF) asm volatile("" : "+v"(o[k]));
+#ifndef AGZ_X_PROLOGUE_STAMP
+    G4_STAMP(6);
+#endif
     if (res) {                                    // the residual tile has landed, for every wave
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+#ifndef AGZ_X_PROLOGUE_STAMP
+    G4_STAMP(7);
+#endif
     // img = (residual +) value.  ds_add_f32 would do the sum in one instruction, but LDS float atomics run at a
     // fraction of the ds_write rate (+0.75 ms per layer measured): read the nine residuals of a row, add, write
     auto rows = [&](auto with_res) {
@@ -543,6 +626,7 @@ __device__ __forceinline__ void wino_wg(
     else rows(std::false_type{});
   }
   __syncthreads();
+  G4_STAMP(3);
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   if (pass1b) {
     // phase 1b: element = (row, k, 4 channels); 16 consecutive lanes cover the 256 contiguous bytes of one point
@@ -565,7 +649,8 @@ __device__ __forceinline__ void wino_wg(
         if ((MODE & 1) && offs[i0 + j] >= 0) *reinterpret_cast<f32x4*>(y + offs[i0 + j] + cg4) = v[j];
     }
   }
-  if (!(MODE & 2)) return;
+  G4_STAMP(4);
+  if (!(MODE & 2) || X == 2) return;
 
   // ---- phase 2: the next layer's input transform for this workgroup's 64 channels (= stages 16 cb .. 16 cb + 15
   // of the next layer's K loop).  Task = (tile row, stage): lane = row, so that the 64 lanes of a wave fill 64
@@ -623,7 +708,7 @@ __device__ __forceinline__ void wino_wg(
           d[q] = (f32x4){a[0], a[1], b[0], b[1]};
         }
       }
-      float* g = vnext + ((long)tb * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
+      float* g = vnext + ((long)((X == 16 || X == 18) ? (tb & 63) : tb) * WNS + (cb * (WC / WK) + sl)) * A_STAGE + row * 4;
       // B^T d B on channel PAIRS (v_pk_*_f32: two channels per VALU instruction; no MFMA runs beside this): the
       // arithmetic of bt5 above, operation for operation (9 packed operations per five values)
       auto bt5p = [](f32x2 x0, f32x2 x1, f32x2 x2, f32x2 x3, f32x2 x4, f32x2* r) {      // bt5, two channels at a time
@@ -650,13 +735,18 @@ __device__ __forceinline__ void wino_wg(
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
           f32x2 r[5];
-          bt5p(tx[i * 5 + 0], tx[i * 5 + 1], tx[i * 5 + 2], tx[i * 5 + 3], tx[i * 5 + 4], r);
+          if (X == 7 || X == 10) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) r[j] = tx[i * 5 + j];
+          } else {
+            bt5p(tx[i * 5 + 0], tx[i * 5 + 1], tx[i * 5 + 2], tx[i * 5 + 3], tx[i * 5 + 4], r);
+          }
 #pragma unroll
           for (int j = 0; j < 5; ++j) vv[i * 5 + j][h] = r[j];
         }
       }
 #pragma unroll
-      for (int xi = 0; xi < WXI; ++xi) {      // (the 26th plane slot of an image is padding nobody multiplies with)
+      for (int xi = 0; xi < ((X == 7 || X == 10) ? 15 : WXI); ++xi) {      // (the 26th plane slot of an image is padding nobody multiplies with)
         const f32x2 p0 = vv[xi][0], p1 = vv[xi][1];
         f32x4 v4;
         if constexpr (SPLIT) {
@@ -671,13 +761,18 @@ __device__ __forceinline__ void wino_wg(
           v4 = (f32x4){p0[0], p0[1], p1[0], p1[1]};        // (already in the row's pair order: see the reads above)
         }
         f32x4* gp = reinterpret_cast<f32x4*>(g + (xi >> 1) * (WT * 8) + (xi & 1) * (WT * 4));
+        if (X == 3) {
+          if (v4[0] + v4[3] == 123.456f) *gp = v4;
+          continue;
+        }
         if (emit) __builtin_nontemporal_store(v4, gp);      // 1.9 GB per layer, read back a whole layer later: keep it out of L2
       }
     }
   }
+  G4_STAMP(5);
 }
 
-template <int MODE, bool SPLIT = false, int NS = WNS>
+template <int MODE, int X = 0, bool SPLIT = false, int NS = WNS>
 __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
     const float* __restrict__ vimg, const float* __restrict__ uimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
@@ -695,7 +790,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_gemm4(
   const int cb = jb & 3;
   const int tb = tb0 + xcd + 8 * (jb >> 2);      // this launch covers tile blocks [tb0, tb1) (launch_wino_gemm: part / parts)
   if (tb >= tb1 || (long)tb * wino_rows_per_block(T) >= Mt) return;
-  wino_wg<SPLIT, NS, false>(lds, ptab, vimg, uimg, scale, shift, res, y, vnext, Mt, N, T, relu, tb, cb, MODE, (int)threadIdx.x);
+  wino_wg<X, SPLIT, NS, false>(lds, ptab, vimg, uimg, scale, shift, res, y, vnext, Mt, N, T, relu, tb, cb, MODE, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------ the whole tower in one launch
@@ -747,11 +842,19 @@ __global__ __launch_bounds__(256, 1) void k_wino_tower(const TowerLayer* __restr
   const int nbx = blocks > xcd ? (blocks - xcd + 7) >> 3 : 0;
   const int total = nl * nbx;
   int* done = sched + kTowerDone;
+#ifdef AGZ_TIMING_EXPERIMENTS
+  long long tw_wait = 0, tw_body = 0, tw_fin = 0, tw_items = 0;
+  const long long tw_t0 = wall_clock64();
+#define TW_NOW() ((long long)wall_clock64())
+#endif
   // order 0: the XCD's list layer-major (every quad on the same layer, a tile block's next layer ~18 items later);
   // order 1: chain-major -- a quad takes a tile block through ALL layers before its next one, so the V it reads was
   // written one item earlier (by itself) and is still in the Infinity Cache
   const int nitems = order == 0 ? (total > quad ? (total - quad + 7) >> 3 : 0) : (nbx > quad ? ((nbx - quad + 7) >> 3) * nl : 0);
   for (int k = 0; k < nitems; ++k) {
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const long long tw_a = TW_NOW();
+#endif
     int l, tb;
     if (order == 0) {
       const int item = quad + 8 * k;
@@ -779,13 +882,19 @@ __global__ __launch_bounds__(256, 1) void k_wino_tower(const TowerLayer* __restr
     }
     __syncthreads();      // the dependency is in; and every wave has left the previous item's epilogue (image, ptab)
     if (s_bc) return;     // (uniform: the forward's output is garbage and Net::forward reports the error word)
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const long long tw_b = TW_NOW();
+#endif
     const TowerLayer L = layers[l];
     // the thread id through an opaque asm: everything the body derives from it (lane offsets, LDS addresses, tables) is
     // recomputed per item -- a handful of VALU instructions -- instead of being hoisted out of this loop and spilled
     // (41 VGPRs in scratch when left to the compiler: the body owns all 512 registers)
     int t = tid;
     asm volatile("" : "+v"(t));
-    wino_wg<SPLIT, WNS, true>(lds, ptab, L.v, L.u, L.scale, L.shift, L.res, L.y, L.vnext, Mt, N, T, L.relu, tb, cb, L.mode, t);
+    wino_wg<0, SPLIT, WNS, true>(lds, ptab, L.v, L.u, L.scale, L.shift, L.res, L.y, L.vnext, Mt, N, T, L.relu, tb, cb, L.mode, t);
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const long long tw_c = TW_NOW();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have reached L2
     __syncthreads();
     if (tid == 0) {
@@ -797,7 +906,22 @@ __global__ __launch_bounds__(256, 1) void k_wino_tower(const TowerLayer* __restr
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 && ++spins < kTowerSpinLimit) __builtin_amdgcn_s_sleep(2);
       }
     }
+#ifdef AGZ_TIMING_EXPERIMENTS
+    const long long tw_d = TW_NOW();
+    if (tid == 0 && slot < 4 && tw_items < 384) {      // the first quad of every XCD: every item's {start, end, layer, tile block}
+      unsigned long long* r = g4_trace[256 + (xcd * 4 + slot) * 384 + tw_items];
+      r[0] = tw_b; r[1] = tw_c; r[2] = l; r[3] = tb;
+    }
+    tw_wait += tw_b - tw_a; tw_body += tw_c - tw_b; tw_fin += tw_d - tw_c; ++tw_items;
+#endif
   }
+#ifdef AGZ_TIMING_EXPERIMENTS
+  if (tid == 0) {      // per persistent workgroup: {xcd | slot << 8, items, wait, body, finish, start, end} (10 ns ticks)
+    unsigned long long* r = g4_trace[blockIdx.x];
+    r[0] = (unsigned long long)xcd | ((unsigned long long)slot << 8);
+    r[1] = tw_items; r[2] = tw_wait; r[3] = tw_body; r[4] = tw_fin; r[5] = tw_t0; r[6] = TW_NOW();
+  }
+#endif
 }
 
 // one workgroup per CU: which XCD does block b run on?  (the tower kernel does not depend on the answer being b % 8,
@@ -932,21 +1056,50 @@ void launch_wino_gemm(const float* vimg, const float* uimg, const float* scale, 
   if (ns == kWinoStemStages) {                   // the stem: its output is always wanted in HBM (block 0's residual)
     constexpr int S = kWinoStemStages;
     if (split) {
-      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
-      else hipLaunchKernelGGL((k_wino_gemm4<1, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, 0, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      else hipLaunchKernelGGL((k_wino_gemm4<1, 0, true, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     } else {
-      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
-      else hipLaunchKernelGGL((k_wino_gemm4<1, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      if (vnext) hipLaunchKernelGGL((k_wino_gemm4<3, 0, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      else hipLaunchKernelGGL((k_wino_gemm4<1, 0, false, S>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     }
     return;
   }
+#ifdef AGZ_TIMING_EXPERIMENTS
+  static const int xp = getenv("AGZ_WINO_X") ? atoi(getenv("AGZ_WINO_X")) : 0;
+  static int traced = 0;
+  if (getenv("AGZ_WINO_TRACE") && y && vnext && res && !split && ++traced == 3) {      // third steady-state layer launch
+    hipLaunchKernelGGL((k_wino_gemm4<3>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[16384][8];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_trace), sizeof(host));
+    if (FILE* f = fopen(getenv("AGZ_WINO_TRACE"), "wb")) {
+      fwrite(host, 1, sizeof(host), f);
+      fclose(f);
+    }
+    return;
+  }
+  if (xp && y && vnext && res && split) {
+    auto kern = xp == 1 ? k_wino_gemm4<3, 1, true> : xp == 2 ? k_wino_gemm4<3, 2, true> : xp == 3 ? k_wino_gemm4<3, 3, true>
+              : xp == 5 ? k_wino_gemm4<3, 5, true> : k_wino_gemm4<3, 0, true>;
+    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+    return;
+  }
+  if (xp && y && vnext && res && !split) {
+    auto kern = xp == 1 ? k_wino_gemm4<3, 1> : xp == 2 ? k_wino_gemm4<3, 2> : xp == 3 ? k_wino_gemm4<3, 3>
+              : xp == 4 ? k_wino_gemm4<3, 4> : xp == 5 ? k_wino_gemm4<3, 5> : xp == 6 ? k_wino_gemm4<3, 6>
+              : xp == 16 ? k_wino_gemm4<3, 16> : xp == 17 ? k_wino_gemm4<3, 17> : xp == 18 ? k_wino_gemm4<3, 18> : xp == 13 ? k_wino_gemm4<3, 13> : xp == 14 ? k_wino_gemm4<3, 14> : xp == 15 ? k_wino_gemm4<3, 15> : xp == 7 ? k_wino_gemm4<3, 7> : xp == 8 ? k_wino_gemm4<3, 8> : xp == 9 ? k_wino_gemm4<3, 9> : xp == 10 ? k_wino_gemm4<3, 10>
+              : xp == 11 ? k_wino_gemm4<1, 0> : xp == 12 ? k_wino_gemm4<2, 0> : k_wino_gemm4<3, 0>;
+    hipLaunchKernelGGL(kern, grid, block, 0, s, vimg, uimg, scale, shift, xp == 12 ? nullptr : res, y, vnext, d_count, N, T, relu, tb0, tb1);
+    return;
+  }
+#endif
   if (split) {
     if (y && vnext)
-      hipLaunchKernelGGL((k_wino_gemm4<3, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      hipLaunchKernelGGL((k_wino_gemm4<3, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     else if (vnext)
-      hipLaunchKernelGGL((k_wino_gemm4<2, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      hipLaunchKernelGGL((k_wino_gemm4<2, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     else
-      hipLaunchKernelGGL((k_wino_gemm4<1, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
+      hipLaunchKernelGGL((k_wino_gemm4<1, 0, true>), grid, block, 0, s, vimg, uimg, scale, shift, res, y, vnext, d_count, N, T, relu, tb0, tb1);
     return;
   }
   if (y && vnext)
@@ -994,11 +1147,27 @@ void launch_wino_tower(const void* d_layers, int layers, int* d_sched, const int
               "batch of %d positions at %dx%d: tile index / activation byte offset exceeds 32 bits", bcap, N, N);
   const int blocks_cap = (int)wino_blocks(bcap, T);
   (void)hipMemsetAsync(d_sched, 0, sizeof(int) * wino_tower_sched_ints(layers, bcap, N), s);
+#ifdef AGZ_TIMING_EXPERIMENTS
+  static const int order = getenv("AGZ_TOWER_ORDER") ? atoi(getenv("AGZ_TOWER_ORDER")) : 0;
+#else
   constexpr int order = 0;
+#endif
   if (split)
     hipLaunchKernelGGL((k_wino_tower<true>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T, order);
   else
     hipLaunchKernelGGL((k_wino_tower<false>), dim3(256), dim3(256), 0, s, (const TowerLayer*)d_layers, layers, d_sched, blocks_cap, d_count, N, T, order);
+#ifdef AGZ_TIMING_EXPERIMENTS
+  static int traced = 0;
+  if (getenv("AGZ_TOWER_TRACE") && ++traced == 3) {
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[256 + 32 * 384][8];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_trace), sizeof(host));
+    if (FILE* f = fopen(getenv("AGZ_TOWER_TRACE"), "wb")) {
+      fwrite(host, 1, sizeof(host), f);
+      fclose(f);
+    }
+  }
+#endif
 }
 
 }  // namespace agz
