@@ -25,6 +25,7 @@ struct HipWave {
   static constexpr bool kRegisterRows = true;     // select_leaf_rows (agz_search.h)
   int lane;
   __device__ HipWave() : lane((int)threadIdx.x) {}
+  __device__ explicit HipWave(int l) : lane(l) {}      // (a wave of a multi-wave workgroup: kernels that never call sync())
   template <class F>
   __device__ __forceinline__ void for_each(int n, F f) const {
     for (int i = lane; i < n; i += kWave) f(i);
@@ -186,12 +187,21 @@ __global__ __launch_bounds__(256) void k_scan(View V) {
   }
 }
 
-__global__ __launch_bounds__(kWave) void k_leaf_features(View V, int g0, float* x32, float* whcn) {
-  const int g = g0 + blockIdx.x / V.par, k = blockIdx.x % V.par;
+// One workgroup of four waves per leaf slot, each wave a quarter of the leaf's (point, quad) items.  Round 6 rewrote this
+// kernel three times and timed each (bench.py's search_kernels): coalesced 1 KB store runs instead of 64 lines 128 B apart
+// (35.5 -> 34.8 us per 8192 leaves of 9x9: the stores were not the bound), four leaves per workgroup (37.3: nor the dispatch
+// rate), and this form: a lone wave walks its leaf in eleven dependent load -> store rounds, so the kernel is as long as
+// eleven memory latencies whatever the bandwidth; four waves per leaf make it three.
+constexpr int kWavesPerLeaf = 4;
+__global__ __launch_bounds__(kWavesPerLeaf * kWave) void k_leaf_features(View V, int g0, int slots, float* x32, float* whcn) {
+  const int slot = (int)blockIdx.x;
+  if (slot >= slots) return;
+  const int g = g0 + slot / V.par, k = slot % V.par;
   if (k >= V.gs[g].nleaves) return;
-  HipWave w;
+  HipWave w((int)(threadIdx.x & (kWave - 1)));
   const long row = (long)V.gs[g].leaf_base + k;
-  leaf_features(w, V, g, k, x32 ? x32 + row * V.P * 32 : nullptr, whcn ? whcn + row * 17 * V.P : nullptr);
+  leaf_features(w, V, g, k, x32 ? x32 + row * V.P * 32 : nullptr, whcn ? whcn + row * 17 * V.P : nullptr, (int)(threadIdx.x >> 6),
+                kWavesPerLeaf);
 }
 
 // The Vector{Position} a caller-supplied network receives (mcts_play.jl:89): per collected leaf of slot g, its own
@@ -534,7 +544,7 @@ void Engine::step(int nsteps) {
     if (ev) (void)hipEventRecord(ev[2], stream_);
     hipLaunchKernelGGL(cfg_.arena_mode ? k_scan_arena : k_scan, dim3(1), dim3(256), 0, stream_, V_);
     if (ev) (void)hipEventRecord(ev[3], stream_);
-    hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWave), 0, stream_, V_, 0, d_x32_.p, (float*)nullptr);
+    hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWavesPerLeaf * kWave), 0, stream_, V_, 0, bcap_, d_x32_.p, (float*)nullptr);
     if (ev) (void)hipEventRecord(ev[4], stream_);
     if (cfg_.arena_mode) {   // evaluate(): Black's players ask network 0, White's network 1
       const int half = bcap_ / 2;
@@ -600,7 +610,7 @@ void Engine::leaf_features_external(float* feats_out) {
   if (B + B2 <= 0) return;
   const size_t per = (size_t)17 * V_.P;
   d_whcn_.ensure((size_t)bcap_ * per);
-  hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWave), 0, stream_, V_, 0, (float*)nullptr, d_whcn_.p);
+  hipLaunchKernelGGL(k_leaf_features, dim3(bcap_), dim3(kWavesPerLeaf * kWave), 0, stream_, V_, 0, bcap_, (float*)nullptr, d_whcn_.p);
   if (B) AGZ_HIP(hipMemcpyAsync(feats_out, d_whcn_.p, sizeof(float) * (size_t)B * per, hipMemcpyDeviceToHost, stream_));
   // arena: the White players' rows follow the Black players' rows in the host buffer
   if (B2) AGZ_HIP(hipMemcpyAsync(feats_out + (size_t)B * per, d_whcn_.p + (size_t)(bcap_ / 2) * per,
@@ -1374,7 +1384,7 @@ void Engine::tree_leaf_features(int g, float* feats_out) {
   check_game(g);
   if (tree_batch_ <= 0) return;
   d_whcn_.ensure((size_t)bcap_ * 17 * V_.P);
-  hipLaunchKernelGGL(k_leaf_features, dim3(V_.par), dim3(kWave), 0, stream_, V_, g, (float*)nullptr, d_whcn_.p);
+  hipLaunchKernelGGL(k_leaf_features, dim3(V_.par), dim3(kWavesPerLeaf * kWave), 0, stream_, V_, g, V_.par, (float*)nullptr, d_whcn_.p);
   AGZ_HIP(hipMemcpyAsync(feats_out, d_whcn_.p, sizeof(float) * (size_t)tree_batch_ * 17 * V_.P,
                          hipMemcpyDeviceToHost, stream_));
   AGZ_HIP(hipStreamSynchronize(stream_));
@@ -1431,7 +1441,7 @@ int Engine::tree_search_incorporate(int g, const float* pi, const float* v) {
     } else {
       d_count_.ensure(1);
       AGZ_HIP(hipMemcpyAsync(d_count_.p, &n, sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-      hipLaunchKernelGGL(k_leaf_features, dim3(V_.par), dim3(kWave), 0, stream_, V_, g, d_x32_.p, (float*)nullptr);
+      hipLaunchKernelGGL(k_leaf_features, dim3(V_.par), dim3(kWavesPerLeaf * kWave), 0, stream_, V_, g, V_.par, d_x32_.p, (float*)nullptr);
       net_->forward(d_x32_.p, d_count_.p, std::min(bcap_, V_.par), d_pi_.p, d_v_.p);
     }
   }

@@ -1356,7 +1356,8 @@ AGZ_FN void game_post(W& w, const View& V, Scratch& S, int g) {
 
 // Feature planes of one leaf slot into the stem-input layout [P][32] (features.jl:3-26)
 template <class W>
-AGZ_FN void leaf_features(W& w, const View& V, int g, int k, float* x32, float* whcn) {
+// part / parts: this wave does the part-th of `parts` equal shares of the leaf's items (k_leaf_features gives a leaf four waves)
+AGZ_FN void leaf_features(W& w, const View& V, int g, int k, float* x32, float* whcn, int part = 0, int parts = 1) {
   const long li = (long)g * V.par + k;
   const int tp = V.leaf_tp[li];
   const int P = V.P;
@@ -1373,7 +1374,9 @@ AGZ_FN void leaf_features(W& w, const View& V, int g, int k, float* x32, float* 
     // and a lane reads the two board bytes its quad needs instead of all eight.
     struct alignas(16) Quad { float a, b, c, d; };
     Quad* dst = reinterpret_cast<Quad*>(x32);
-    w.for_each(P * 8, [&](int i) {
+    const int per = (P * 8 + parts - 1) / parts, lo = part * per, hi = lo + per < P * 8 ? lo + per : P * 8;
+    w.for_each(hi - lo, [&](int j) {
+      const int i = lo + j;
       const int p = i >> 3, c = i & 7;
       Quad q{0.f, 0.f, 0.f, 0.f};
       if (c < 4) {
@@ -1388,8 +1391,10 @@ AGZ_FN void leaf_features(W& w, const View& V, int g, int k, float* x32, float* 
       dst[i] = q;
     });
   }
-  if (whcn)
-    w.for_each(P, [&](int p) {
+  if (whcn) {
+    const int per = (P + parts - 1) / parts, lo = part * per, hi = lo + per < P ? lo + per : P;
+    w.for_each(hi - lo, [&](int j) {
+      const int p = lo + j;
       for (int s = 0; s < 8; ++s) {
         const int c = stone(s, p);
         whcn[(long)P * (2 * s) + p] = c == tp ? 1.f : 0.f;
@@ -1397,6 +1402,7 @@ AGZ_FN void leaf_features(W& w, const View& V, int g, int k, float* x32, float* 
       }
       whcn[(long)P * 16 + p] = (float)tp;
     });
+  }
 }
 
 

@@ -41,17 +41,18 @@ def pmc_traffic(rows_per_launch, N, precision="f32", f43=False):
     """HBM bytes per tower-conv launch, from the committed rocprofv3 --pmc passes.
 
     Hardware counters cannot be read from inside this process; FETCH_SIZE and WRITE_SIZE were collected in two
-    separate `rocprofv3 --pmc` runs of THIS command (tools/profile_r05.sh: same kernels, same batch) and summarised
+    separate `rocprofv3 --pmc` runs of THIS command (tools/profile_r06.sh: same kernels, same batch) and summarised
     by tools/pmc_traffic.py as bytes per board-point row.  Scaled here by the average rows per launch of THIS run.
     The newest round's file for the board size and precision wins; the F(4x4,3x3) tower (19x19 f32 since round 4) only
     takes a round-4 or later file.  None if no file exists."""
-    names = [f"r05_pmc_traffic_{N}x{N}_{precision}.json", f"r04_pmc_traffic_{N}x{N}_{precision}.json"]
+    names = [f"r06_pmc_traffic_{N}x{N}_{precision}.json", f"r05_pmc_traffic_{N}x{N}_{precision}.json",
+             f"r04_pmc_traffic_{N}x{N}_{precision}.json"]
     if not f43:
         names.append(f"r03_pmc_traffic_{N}x{N}_{precision}.json")
         if N == 9:
             names.append("pmc_traffic.json" if precision == "f32" else f"r02_pmc_traffic_{precision}.json")
     if N >= 13 and precision == "f32" and not f43:
-        names = names[2:]              # (--winograd 2 on a large board: the round-3 kernel's file)
+        names = names[3:]              # (--winograd 2 on a large board: the round-3 kernel's file)
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         try:

@@ -16,13 +16,15 @@
 // The reduction order of an output is fixed (chunk, tap, k) and does not depend on where its row sits in the
 // batch: tree parity with the oracle (which calls this network) stays bit-exact.
 //
-// What is in this file: THE PRODUCT and nothing else -- k_conv3x3_f16_q<RES> (2 x 2 waves over 256-row x 256-cout tiles) for the
-// half-in / half-out layers, k_conv3x3_f16_w2<RES, OUTF> (7 x 2 wave tiles over 224 rows) for the f32-residual and f32-output
-// layers, the weight-image and conversion kernels.  No environment variable is read here (tests/test_build_invariants.py).
-// The measurement apparatus of rounds 2-5 (timing and measurement variants -- results WRONG --, store policies, pacing, the
-// LDS weight ring, register masking, the zero-block form) lives in tools/experiments/agz_conv16_variants.hip, the file this
-// one was until round 6; tools/build_timing_lib.sh (ALSO=agz_conv16) compiles it in place of this file, so the tables of
-// HISTORY.md 4b / 4h / 12 can still be re-run.
+// What is in this file.  THE PRODUCT is k_conv3x3_f16_q<RES> (2 x 2 waves over 256-row x 256-cout tiles) for the half-in /
+// half-out layers and k_conv3x3_f16_w2<0, RES, OUTF, 7, false, false, 0> (7 x 2 wave tiles over 224 rows) for the f32-residual
+// and f32-output layers, plus the weight-image and conversion kernels: the only forms a product build instantiates, and the
+// product library reads NO environment variable here (tests/test_build_invariants.py holds both).  The template parameters
+// beyond those are measurement apparatus kept so that the tables in HISTORY.md 4b / 4h / 12 can be re-run on the same
+// source; they are instantiated and selectable only in a timing build (make EXTRA=-DAGZ_TIMING_EXPERIMENTS, see
+// launch_conv16_experiments): AGZ_C16_DM, AGZ_C16_Q / _QZ (bit-identical forms), AGZ_C16_POLICY, AGZ_C16_MEAS,
+// AGZ_C16_DEBUG / _RB / _PACE (results WRONG: parts of the loop compiled out), and -DAGZ_C16_WL=true (weights through a
+// wave-private LDS ring, round 4).
 #include "agz_nn.h"
 
 #include <hip/hip_fp16.h>
@@ -124,6 +126,29 @@ void launch_conv16_pack(const float* d_w, long wstride, int layers, uint16_t* d_
   hipLaunchKernelGGL(k_conv16_pack, dim3(grid), dim3(256), 0, s, d_w, wstride, layers, d_out, per);
 }
 
+#ifdef AGZ_TIMING_EXPERIMENTS
+// pacing experiment: bit i set = the waves sleep 64 clocks in k-step i of every channel chunk (AGZ_C16_PACE, 18 bits)
+__device__ unsigned g_c16_pace = 0;
+#endif
+
+// Cache policy of the result stores / residual loads of the trickled epilogue, set once from AGZ_C16_POLICY (round 5
+// experiment, HISTORY.md 12): bits 0-1 = stores plain / sc1 (write-through: the line does not stay in this XCD's L2, where
+// it would push the 1.2 MB of weights every tile re-reads out) / nt / sc0 sc1; bits 3 / 4 (measurement only, WRONG
+// results): drop the trickled result stores of every other workgroup / of all.  (A second switch on the residual loads
+// made the residual-carrying form spill 25 registers: this kernel has no register to give.)
+#ifdef AGZ_TIMING_EXPERIMENTS
+__device__ unsigned g_c16_policy = 0;
+#endif
+typedef unsigned c16_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void c16_store(c16_u4* gp, c16_u4 v, unsigned pol) {
+  switch (pol & 3u) {
+    case 1: asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gp), "v"(v) : "memory"); break;
+    case 2: asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(gp), "v"(v) : "memory"); break;
+    case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(gp), "v"(v) : "memory"); break;
+    default: *gp = v;
+  }
+}
+
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < E) {
@@ -133,31 +158,48 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // RES: 0 = no residual, 1 = half, 2 = f32 (first block's skip); OUTF: the output is f32 (last layer), else half.
-// The product forms: the f32-residual layer (RES 2) and the three f32-output layers (OUTF) of a tower; 7 row blocks of 32 per
-// tile, one workgroup per CU, weight fragments 8 k-steps ahead through a ring of 9 register sets, residual and result across
-// wave-private LDS tiles (the direct epilogue).  Everything else this kernel has been -- the half-in / half-out form with its
-// trickled result image (rounds 2-4; those layers run k_conv3x3_f16_q since round 5), the weight ring in LDS (WL), register
-// masking of off-board fragments (DM), four row blocks with two workgroups per CU, the timing (DBG) and measurement (MEAS)
-// variants, store policies and pacing -- is in tools/experiments/agz_conv16_variants.hip, which tools/build_timing_lib.sh
-// compiles in place of this file (HISTORY.md 4b, 4h, 12).
-template <int RES, bool OUTF>
-__global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
+// DBG (timing variants, -DAGZ_TIMING_EXPERIMENTS, wrong results): bit mask of what is compiled out -- 1 epilogue,
+// 2 weight loads, 4 LDS operand reads, 8 slab DMA, 16 MFMA, 32 result stores; 64 = the stores go to 64 fixed (L2-resident)
+// regions; 128 = non-temporal result stores; 256 = streaming weight loads; 512 = the weight stream as LDS-DMA (into LDS, unused).
+// RB: row blocks of 32 per tile -- 7 (one workgroup per CU, results leave through the LDS image) or 4 (two workgroups
+// per CU, direct epilogue)
+// WL: the weight fragments reach the wave through a wave-private LDS ring filled by LDS-DMA (and the results leave through
+// the direct epilogue) instead of global_load -> registers + the trickled result image: see "Round 4" below.
+// DM (round 5, AGZ_C16_DM=1): a lane whose neighbour is off the board reads the slab like every other lane -- the address
+// it computes lies inside the slab, the halo guarantees that -- and the fragment is zeroed in registers (v_cndmask on a
+// lane mask) instead of the ADDRESS being switched to a shared row of zeros.  The slab reads become conflict-free whatever
+// the tile's share of edge points (SQ_LDS_BANK_CONFLICT 0.29 -> 0.04 of the LDS cycles), a row block's address is one
+// base register plus an immediate, and seven address registers go away.  (The first form of this, a 256-byte zero block
+// read at the real address modulo 256, removed the conflicts too and cost 16-18 spilled registers, each reload a
+// vmcnt(0) behind 17 k-steps of weight loads in flight: +4.7 % cycles, profiles/r05_c16_zb_*.)
+// MEAS (round 5, AGZ_C16_MEAS=<mask>; measurement only, results WRONG): parts of the tile loop compiled out WITHOUT changing
+// what the MFMAs multiply -- 32: the weight fragments of one full ring fill are reused (no re-loads), 64: the slabs of chunks 0
+// and 1 are reused (no further slab DMA), 128: the slab fragments read for the first k-step are reused (no LDS operand
+// reads), 256: no epilogue arithmetic.  (The result stores are dropped at run time: AGZ_C16_POLICY bits 3 / 4.)  Round 4's
+// variants (DBG) left activation buffers unwritten or operand registers constant: their MFMAs multiplied zeros or constants,
+// and a matrix pipe's power follows its operands (HISTORY.md 12).
+template <int DBG, int RES, bool OUTF, int RB, bool WL, bool DM, int MEAS = 0>
+__global__ __launch_bounds__(256, RB <= 4 ? 2 : 1) void k_conv3x3_f16_w2(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const void* __restrict__ res, void* __restrict__ y,
                                                          const int* __restrict__ d_count, int N, int relu) {
   constexpr bool RESF = RES == 2;
-  static_assert(RESF || OUTF, "the half-in / half-out layers are k_conv3x3_f16_q's");
-  constexpr int RB = W2_RB_PRODUCT, W2_RB = RB, W2_HM = 32 * RB;
+  constexpr bool TRICKLE = !WL && RB == W2_RB_PRODUCT && !RESF && !OUTF && !(DBG & 1024);      // (1024: timing variant, direct epilogue)
+  constexpr int W2_RB = RB, W2_HM = 32 * RB;
   constexpr int W2_SLABCH = ((W2_HM + 2 * 20) * 4 + 63) / 64, NPJ = (W2_SLABCH + 3) / 4;
   constexpr int W2_SLAB = W2_SLABCH * 512, W2_SLABS = W2_SLAB + 32;
   constexpr int W2_OFF_SC = 2 * W2_SLABS, W2_OFF_OUT = W2_OFF_SC + 1024;
   constexpr int TINB = RES == 0 ? 0 : (RESF ? 32 * 272 : 32 * 144), TOUTB = OUTF ? 32 * 272 : 32 * 144;   // direct epilogue tiles
-  constexpr int W2_OUTB = 4 * (TINB + TOUTB);
-  constexpr int W2_SMEM = W2_OFF_OUT + W2_OUTB / 2;
-  // weight fragments 8 k-steps ahead through a ring of 9 register sets (with 17 / 18 these forms spill 29-44 registers, and
-  // a reload, even outside any loop, is a wait behind every weight load in flight)
-  constexpr int W2_D = 8, W2_RING = W2_D + 1;
-  static_assert(W2_OFF_OUT % 64 == 0 && 18 % W2_RING == 0, "layout");
+  constexpr int W2_OUTB = TRICKLE ? 4 * RB * 4096 : 4 * (TINB + TOUTB);
+  // WL: a ring of WD k-steps of this wave's two fragments (2 KB per k-step) in LDS; W2_D = how far ahead the fetch runs
+  constexpr int WD = 6;
+  constexpr int W2_OFF_W = (W2_OFF_OUT + W2_OUTB / 2 + 63) / 64 * 64;
+  constexpr int W2_SMEM = WL ? W2_OFF_W + 4 * WD * 1024 : W2_OFF_OUT + W2_OUTB / 2;
+  // DM, and the two direct-epilogue layers of a tower (f32 residual in: first block; f32 out: last): weight fragments 8
+  // k-steps ahead through a ring of 9 register sets instead of 17 / 18 (72 registers back) -- with the 17-deep ring those forms
+  // spill 29-44 registers, and a reload, even outside any loop, is a wait behind every weight load in flight
+  constexpr int W2_D = WL ? WD - 1 : (RB <= 4 ? 5 : ((DM || RESF || OUTF) ? 8 : 17)), W2_RING = WL ? 2 : W2_D + 1;
+  static_assert(W2_OFF_OUT % 64 == 0 && 18 % W2_RING == 0 && 18 % WD == 0 && W2_KS % WD == 0, "layout");
   static_assert(W2_SMEM * 2 <= 160 * 1024, "LDS");
   // direct epilogue tiles [32 rows][64 couts]: row stride / 16-byte pieces per row / pieces per lane, per element type
   constexpr int RSB = RESF ? 272 : 144, RPR = RESF ? 16 : 8, RNP = RESF ? 8 : 4;
@@ -221,24 +263,87 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
   f32x16 acc[W2_RB][2];
   h8 A[W2_RB], Bf[W2_RING][2];
   int aaddr[W2_RB];
+  int abase = 0;                                          // DM: one address for the seven row blocks (+ rbk * 2048 as an immediate)
   auto tap_addr = [&](int sbuf, int tapi) __attribute__((always_inline)) {
     const int off = (tapi % 3 - 1) + N * (tapi / 3 - 1);
     const int base = sbuf * (W2_SLABS * 2);
     const int R0 = l31 + halo + off;
     const int a0 = base + (R0 << 6) + ((((R0 >> 2) ^ hi) & 3) << 4);      // row block rbk: + rbk * 2048, same swizzle
+    if (DM) {
+      abase = a0;
+    } else {
 #pragma unroll
-    for (int rbk = 0; rbk < W2_RB; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : base + W2_SLAB * 2;
+      for (int rbk = 0; rbk < W2_RB; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : base + W2_SLAB * 2;
+    }
   };
   // (one register set: a row block's fragment of the next k-step is fetched right after the block's two MFMAs)
   auto read_a = [&](int ks, int rbk) __attribute__((always_inline)) {
-    A[rbk] = *reinterpret_cast<const h8*>(sm + (aaddr[rbk] ^ (ks << 5)));
+    if (DM) A[rbk] = *reinterpret_cast<const h8*>(sm + (abase ^ (ks << 5)) + rbk * 2048);
+    else A[rbk] = *reinterpret_cast<const h8*>(sm + (aaddr[rbk] ^ (ks << 5)));
+  };
+  // DM: the fragment of row block rbk as it arrived, zeroed where tap `tapi`'s neighbour is off the board (or past the batch)
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  auto mask_a = [&](int tapi, int rbk) __attribute__((always_inline)) {
+    unsigned t = vm[rbk];
+    asm volatile("" : "+v"(t));          // (recomputed per k-step: kept for the tap's second k-step the seven masks cost seven registers)
+    const unsigned m = (unsigned)(((int)(t << (31 - tapi))) >> 31);      // all ones if bit tapi is set
+    u4v raw = __builtin_bit_cast(u4v, A[rbk]);
+    raw[0] &= m; raw[1] &= m; raw[2] &= m; raw[3] &= m;
+    A[rbk] = __builtin_bit_cast(h8, raw);
   };
   const char* wfw = reinterpret_cast<const char*>(wf) + wave * 2048;
   auto load_b = [&](int slot, const char* wbase, int kk) __attribute__((always_inline)) {   // this wave's two fragments of k-step kk
     const char* p = wbase + (size_t)kk * 8192;
-    Bf[slot][0] = *reinterpret_cast<const h8*>(p + wlane);
-    Bf[slot][1] = *reinterpret_cast<const h8*>(p + 1024 + wlane);
+    if (WL) {             // `slot` = ring slot kk % WD: 1 KB per fragment, lane * 16 within it
+      const unsigned dst = s0 + (unsigned)(W2_OFF_W + (wave * WD + slot) * 1024) * 2u;
+      glds16hs(p, wlane, dst);
+      glds16hs(p + 1024, wlane, dst + 1024u);
+    } else if (DBG & 512) {      // (timing variant: the weight stream as LDS-DMA into a corner of the result image -- results WRONG)
+      glds16hs(p, wlane, s0 + (unsigned)(W2_OFF_OUT * 2 + wave * 2048));
+      glds16hs(p + 1024, wlane, s0 + (unsigned)(W2_OFF_OUT * 2 + wave * 2048 + 1024));
+    } else if (DBG & 256) {      // (timing variant: streaming weight loads)
+      Bf[slot][0] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(p + wlane));
+      Bf[slot][1] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(p + 1024 + wlane));
+    } else {
+      Bf[slot][0] = *reinterpret_cast<const h8*>(p + wlane);
+      Bf[slot][1] = *reinterpret_cast<const h8*>(p + 1024 + wlane);
+    }
   };
+
+  // WL: this wave's fragments of a k-step from its ring slot into the register pair of that k-step's parity
+  auto read_b = [&](int par, int slot) __attribute__((always_inline)) {
+    const char* q = sm + (W2_OFF_W + (wave * WD + slot) * 1024) * 2 + wlane;
+    Bf[par][0] = *reinterpret_cast<const h8*>(q);
+    Bf[par][1] = *reinterpret_cast<const h8*>(q + 1024);
+  };
+
+  // Result image of the workgroup: [pass 7][32 rows][512 B], a row's thirty-two 16-byte pieces swizzled by the row
+  // (piece q of row r sits at q ^ r).  A wave computes into its own 128-byte slice of every row (pieces wave*8 ..+7);
+  // the image LEAVES in whole rows -- a store instruction is two consecutive 512-byte rows = 1 KB contiguous in HBM,
+  // whichever wave issues it.  (Against wave-private images that leave as 128-byte row segments: the same time within
+  // 0.3 % in an A/B on one box -- the clock the stores cost does not depend on their shape.)
+  char* outw = sm + W2_OFF_OUT * 2;
+  int tr[4];                                               // residual in: this lane's piece i of a pass = row (lane >> 3) + 8 i, column lane & 7 of the slice
+  int tl[4];                                               // image out: row pair wave + 4 i of a pass, lane = (row of the pair, piece)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (lane >> 3) + 8 * i;
+    tr[i] = row * 512 + (((wave * 8 + (lane & 7)) ^ row) << 4);
+    const int orow = 2 * (wave + 4 * i) + (lane >> 5);
+    tl[i] = orow * 512 + (((lane & 31) ^ orow) << 4);
+  }
+  const unsigned tg = (unsigned)((2 * wave + (lane >> 5)) * (kC * 2) + (lane & 31) * 16);     // + i * 4096 + pass * 16384 + tile base
+  const int lx = l31 * 512 + 8 * hi + (((wave * 8) ^ l31) << 4);                              // lane's 8-byte group: lx ^ (piece << 4), piece 0..7 of the slice
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  u4 treg = {0, 0, 0, 0};
+#ifdef AGZ_TIMING_EXPERIMENTS
+  const unsigned pol = __builtin_amdgcn_readfirstlane(g_c16_policy);
+#else
+  constexpr unsigned pol = 0;          // plain stores, nothing dropped: the product has no store-policy switch
+#endif
+  // (measurement only, results WRONG: bit 3 = the result stores of every other workgroup are dropped, bit 4 = of all)
+  const unsigned drop = 16u | ((blockIdx.x & 1u) ? 8u : 0u);
+  char* yprev = nullptr;                                  // tile whose image is leaving: base of its rows in y
 
   int tile = blockIdx.x;
   int m0 = tile * W2_HM;
@@ -246,12 +351,25 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
 #pragma unroll
   for (int j = 0; j < NPJ; ++j) dma_a(0, 0, j);
 #pragma unroll
-  for (int k = 0; k < W2_D; ++k) load_b(k, wfw, k);
+  for (int k = 0; k < ((MEAS & 32) ? W2_RING : W2_D); ++k) load_b(WL ? k % WD : k, wfw, k);
+  if (DBG & (2 | 512)) {      // (timing variants without weight loads into registers: operands that toggle like real ones)
+#pragma unroll
+    for (int sl = 0; sl < W2_RING; ++sl)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Bf[sl][cb][k] = (_Float16)(0.01f * (float)((lane * 7 + sl * 3 + cb * 5 + k) % 37) - 0.18f);
+  }
   tile_masks(m0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   tap_addr(0, 0);
   static_for<0, W2_RB>([&](auto ic) __attribute__((always_inline)) { read_a(0, decltype(ic)::value); });
+  if (WL && !(DBG & 2)) read_b(0, 0);
+  // (the first tile has no predecessor: it sends its own rows' stale image ahead of the real one, same wave, same
+  // addresses, in order -- cheaper than a branch around every piece)
+  yprev = reinterpret_cast<char*>(y) + (size_t)m0 * (kC * 2);
+
   // Residual pieces of the next NRR epilogue passes (a pass is ~1 us of work, an HBM read under load is more).
   // Scalars, not an array: hipcc moves a by-reference captured array into LDS.
   uint4 rr0, rr1, rr2, rr3, rr4, rr5, rr6, rr7, rr8, rr9, rr10, rr11, rr12, rr13, rr14, rr15;
@@ -287,6 +405,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
   };
 
   // one channel chunk: 9 taps x 2 k-steps of 14 MFMAs.  FIRST / LAST chunk of a tile are compile-time.
+#ifdef AGZ_TIMING_EXPERIMENTS
+  const unsigned pace_mask = __builtin_amdgcn_readfirstlane(g_c16_pace);
+#endif
   auto chunk = [&](int cc, auto firstc, auto lastc) __attribute__((always_inline)) {
     constexpr bool first = decltype(firstc)::value, last = decltype(lastc)::value;
     const int sbuf = cc & 1;
@@ -299,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
     for (int rbk = 0; rbk < W2_RB; ++rbk) asm volatile("" : "+v"(vm[rbk]));
     static_for<0, 18>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      constexpr int slot = i % W2_RING;
+      constexpr int slot = WL ? (i & 1) : i % W2_RING;
       constexpr int nks = (i + 1) & 1;
       if (nks == 0) {                                     // the k-step being prefetched opens a new tap
         if (i < 17) tap_addr(sbuf, (i + 1) >> 1);
@@ -307,22 +428,46 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
       }
       int kn = cc * 18 + i + W2_D;
       kn = kn >= W2_KS ? kn - W2_KS : kn;
+#ifdef AGZ_TIMING_EXPERIMENTS
+      if (pace_mask & (1u << i)) __builtin_amdgcn_s_sleep(1);
+#endif
 #pragma unroll
       for (int mi = 0; mi < 2 * W2_RB; ++mi) {
         const int rbk = mi >> 1, cb = mi & 1;
-        if (first && i == 0) {
+        if (DM && cb == 0) mask_a(i >> 1, rbk);
+        if (DBG & 16) {
+          acc[rbk][cb][mi] += (float)Bf[slot][cb][0] * (float)A[rbk][1];
+        } else if (first && i == 0) {
           const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bf[slot][cb], A[rbk], z, 0, 0, 0);
         } else {
           acc[rbk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bf[slot][cb], A[rbk], acc[rbk][cb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (cb == 1 && (i < 17 || !last)) read_a(nks, rbk);
-        if (mi == 2) load_b((i + W2_D) % W2_RING, wb, kn);
+        if (cb == 1 && (i < 17 || !last) && !(DBG & 4) && !(MEAS & 128)) read_a(nks, rbk);
+        if (mi == 2 && !(DBG & 2) && !(MEAS & 32)) load_b(WL ? (i + W2_D) % WD : (i + W2_D) % W2_RING, wb, kn);
+        if (WL && mi == 8 && !(DBG & 2)) {
+          // k-step i + 1's fragments: fetched WD - 2 k-steps ago; the 2 (WD - 2) pieces issued since may be in flight
+          // (anything else issued since -- slab pieces, residual loads -- only makes this wait a little longer)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WD - 2)) : "memory");
+          read_b((i + 1) & 1, (i + 1) % WD);
+        }
         // the next chunk's slab (the next tile's first, in the last chunk) goes out in k-steps 0 and 1
         // (after the last tile the spare buffer just receives the first slab once more: no branch in the loop)
-        if (i < 2 && mi >= 3 && mi < 6 && i * 3 + mi - 3 < NPJ) dma_a(last ? 0 : cc + 1, sbuf ^ 1, i * 3 + mi - 3);
-        if (last && RES != 0 && mi == 2 * RB - 2) {  // the first passes' residual, spread over the last chunk
+        if (!(DBG & 8)) {
+          if (i < 2 && mi >= 3 && mi < 6 && i * 3 + mi - 3 < NPJ && (!(MEAS & 64) || first))
+            dma_a(last ? 0 : cc + 1, sbuf ^ 1, i * 3 + mi - 3);
+        }
+        // chunk cc sends pass cc of the previous tile's image on its way: piece i / 4, read one k-step before it is stored
+        if (TRICKLE && !last && !(DBG & 33) && mi == 12) {
+          if constexpr (i % 4 == 2) treg = *reinterpret_cast<const u4*>(outw + cc * 16384 + tl[i / 4]);
+          if constexpr (i % 4 == 3) {
+            u4* gp = reinterpret_cast<u4*>(yprev + (size_t)cc * (32 * kC * 2) + (i / 4) * 4096 + tg);
+            if (DBG & 128) __builtin_nontemporal_store(treg, gp);      // (timing variant)
+            else if (!(pol & drop)) c16_store(gp, treg, pol);
+          }
+        }
+        if (last && RES != 0 && !(DBG & 1) && mi == 2 * RB - 2) {  // the first passes' residual, spread over the last chunk
           if (i == 4) load_res(std::integral_constant<int, 0>{});
           if (i == 10 && NRR > 1) load_res(std::integral_constant<int, 1>{});
         }
@@ -330,7 +475,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
       }
       if (i == 16) {
         // the slab pieces issued in k-steps 0 and 1 are older than the 2 W2_D weight fragments that may be in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W2_D) : "memory");
+        if (WL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WD - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W2_D) : "memory");
         __syncthreads();
       }
     });
@@ -348,7 +494,55 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
     // cout wave*64 + cb*32 + 8q + 4hi + k
     const float* tab = reinterpret_cast<const float*>(smem + W2_OFF_SC);
     const float lo = relu ? 0.f : -3.0e38f;
-    {
+    if (DBG & 1) {
+      float keep = 0.f;
+#pragma unroll
+      for (int a = 0; a < W2_RB; ++a) keep += acc[a][0][0] + acc[a][1][15];
+      if (keep == 123.456f) reinterpret_cast<float*>(y)[0] = keep;
+    } else if (TRICKLE && (MEAS & 256)) {
+      float keep = 0.f;                                     // (the accumulators stay live; nothing else happens)
+#pragma unroll
+      for (int a = 0; a < W2_RB; ++a) keep += acc[a][0][0] + acc[a][1][15];
+      if (keep == 123.456f) reinterpret_cast<float*>(y)[0] = keep;
+      yprev = reinterpret_cast<char*>(y) + (size_t)m0 * (kC * 2);
+      __syncthreads();
+    } else if (TRICKLE) {
+      // compute only: results (and before them the residual) live in this wave's image, the stores ride on the next tile
+      auto pass = [&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        char* img = outw + r * 16384;
+        if (RES != 0) {
+          static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            *reinterpret_cast<uint4*>(img + tr[i]) = rr(std::integral_constant<int, (r % NRR) * 4 + i>{});
+          });
+          if constexpr (r + NRR < W2_RB) load_res(std::integral_constant<int, r + NRR>{});
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = cb * 32 + 8 * q + 4 * hi;
+            const float4 sc = *reinterpret_cast<const float4*>(tab + wave * 64 + n);
+            const float4 sh = *reinterpret_cast<const float4*>(tab + 256 + wave * 64 + n);
+            h4* t = reinterpret_cast<h4*>(img + (lx ^ ((cb * 4 + q) << 4)));
+            float v0 = acc[r][cb][4 * q + 0] * sc.x + sh.x, v1 = acc[r][cb][4 * q + 1] * sc.y + sh.y;
+            float v2 = acc[r][cb][4 * q + 2] * sc.z + sh.z, v3 = acc[r][cb][4 * q + 3] * sc.w + sh.w;
+            if (RES != 0) {
+              const h4 rv = *t;
+              v0 += (float)rv[0]; v1 += (float)rv[1]; v2 += (float)rv[2]; v3 += (float)rv[3];
+            }
+            v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+            *t = h4{(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+          }
+        asm volatile("" ::: "memory");
+      };
+      static_for<0, W2_RB>(pass);
+      // (timing variant 64: every tile's image leaves for one of 64 fixed tile-sized regions -- the stores stay in L2)
+      yprev = reinterpret_cast<char*>(y) + ((DBG & 64) ? (size_t)(blockIdx.x & 63) * W2_HM : (size_t)m0) * (kC * 2);
+      __syncthreads();                                      // the image is complete: any wave may send any row
+    } else {
       // direct: residual and result cross a wave-private LDS tile each, so that HBM sees 16-byte pieces of whole rows
       char* Tin = sm + W2_OFF_OUT * 2 + wave * TINB;
       char* Tout = sm + W2_OFF_OUT * 2 + 4 * TINB + wave * TOUTB;
@@ -390,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
         for (int i = 0; i < ONP; ++i) {
           const int pc = lane + 64 * i, row = pc / OPR, c16 = pc % OPR;
           const int m = m0 + r * 32 + row;
-          if (m < M)
+          if (m < M && !(DBG & 32))
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + ((size_t)m * kC + wave * 64) * (OUTF ? 4 : 2) + c16 * 16) =
                 *reinterpret_cast<const uint4*>(Tout + row * OSB + c16 * 16);
         }
@@ -405,6 +599,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
     tap_addr(0, 0);
     static_for<0, W2_RB>([&](auto ic) __attribute__((always_inline)) { read_a(0, decltype(ic)::value); });
   }
+  if (TRICKLE && !(DBG & 33)) {                            // the last tile's image
+#pragma unroll
+    for (int r = 0; r < W2_RB; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        c16_store(reinterpret_cast<u4*>(yprev + (size_t)r * (32 * kC * 2) + i * 4096 + tg), *reinterpret_cast<const u4*>(outw + r * 16384 + tl[i]), pol);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -417,14 +618,17 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_w2(const _Float16* __res
 // wave-private 32 x 128 tiles (the result image of a 256-row tile does not fit beside the slabs), weight fragments 8
 // k-steps ahead through a ring of 9.  Same reduction order per output (chunk, tap, k) as the 7 x 2 form: bit-identical results.
 constexpr int QM = 256;                              // rows per tile
-template <int RES>
+// ZB (AGZ_C16_QZ=1, experiment): off-board lanes read zeros from a 256-byte zero block at their real address modulo 256 -- the
+// banks an on-board lane would use -- instead of from one shared zero row: conflict-free slab reads.
+template <int RES, bool ZB = false>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __restrict__ x, const uint16_t* __restrict__ wf,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const _Float16* __restrict__ res, _Float16* __restrict__ y,
                                                          const int* __restrict__ d_count, int N, int relu) {
   constexpr int SLABCH = ((QM + 2 * 20) * 4 + 63) / 64, NPJ = (SLABCH + 3) / 4;      // 1 KB pieces of a slab (halo <= 20 rows a side)
   constexpr int SLAB = SLABCH * 512, SLABS = SLAB + 32;                              // halves; + one 64-byte row of zeros
-  constexpr int OFF_SC = 2 * SLABS, OFF_T = OFF_SC + 1024;
+  constexpr int OFF_Z = (2 * SLABS + 127) / 128 * 128;                               // ZB: 128 halves of zeros, 256-byte aligned
+  constexpr int OFF_SC = ZB ? OFF_Z + 128 : 2 * SLABS, OFF_T = OFF_SC + 1024;
   constexpr int TSB = 264, TB = 32 * TSB;                                            // epilogue tile: 32 rows x 128 halves, row stride 264 B (66 dwords: a lane = row access of 8 bytes is conflict-free)
   constexpr int SMEM = OFF_T + 4 * 2 * TB / 2;
 #ifndef AGZ_C16_QD
@@ -446,6 +650,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
   const int nslabch = (slab * 4 + 63) / 64;
   char* sm = reinterpret_cast<char*>(smem);
   if (tid < 8) reinterpret_cast<uint4*>(smem + (tid >> 2) * SLABS + SLAB)[tid & 3] = make_uint4(0, 0, 0, 0);
+  if (ZB && tid < 16) reinterpret_cast<uint4*>(smem + OFF_Z)[tid] = make_uint4(0, 0, 0, 0);
   {
     float* tab = reinterpret_cast<float*>(smem + OFF_SC);
     tab[tid] = scale[tid];
@@ -494,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f16_q(const _Float16* __rest
     const int base = sbuf * (SLABS * 2);
     const int R0 = wr * 128 + l31 + halo + off;
     const int a0 = base + (R0 << 6) + ((((R0 >> 2) ^ hi) & 3) << 4);
-    const int z0 = base + SLAB * 2;
+    const int z0 = ZB ? OFF_Z * 2 + (a0 & 255) : base + SLAB * 2;          // (row blocks are 2048 bytes apart: same banks)
 #pragma unroll
     for (int rbk = 0; rbk < 4; ++rbk) aaddr[rbk] = ((vm[rbk] >> tapi) & 1u) ? a0 + rbk * 2048 : z0;
   };
@@ -664,6 +869,121 @@ void launch_f32_to_f16(const float* x, uint16_t* y, const int* d_count, int bcap
   hipLaunchKernelGGL(k_f32_to_f16, dim3(grid), dim3(256), 0, s, x, (_Float16*)y, d_count, (long)N * N * kC);
 }
 
+// Round 4: the WL form (weight fragments through a wave-private LDS ring filled by LDS-DMA, six k-steps deep, results
+// through the direct epilogue; -DAGZ_C16_WL=true) was built because two timing variants (512 / 1536: the weight stream
+// as LDS-DMA into unused LDS) ran at 1.08-1.11 ms where the product takes 1.39.  Every fp16 parity test is green with it
+// -- and it takes 1.385 ms: the variants' MFMAs multiplied by a B operand that never changed, and the matrix pipe's
+// power follows its operands' toggling; with real weights in the registers the board is back on its 1305 W limit
+// whichever way they arrive (HISTORY.md 4h).  Kept as a compile-time option, not the product.
+#ifndef AGZ_C16_WL
+#define AGZ_C16_WL false
+#endif
+#ifdef AGZ_TIMING_EXPERIMENTS
+// Timing-experiment dispatch of the fp16 tower layer (never in the product library).  Returns true when it launched.
+//   AGZ_C16_MEAS=32|96|224|480  measurement forms of the no-residual layer (tools/c16_meas.sh; results WRONG)
+//   AGZ_C16_POLICY              cache policy mask of the result stores (tools/c16_policy.sh)
+//   AGZ_C16_Q=0|1|2, AGZ_C16_QZ which form serves the half-in / half-out layers (bit-identical results)
+//   AGZ_C16_DM                  off-board fragments zeroed in registers
+//   AGZ_C16_DEBUG / _RB / _PACE round 2-4 variants: bit mask of what is compiled out (results WRONG)
+static bool launch_conv16_experiments(const _Float16* xh, const uint16_t* wi, const float* scale, const float* shift, const void* res,
+                                      int rk, void* y, int out_f32, const int* d_count, long rows, int ncu, int N, int relu,
+                                      hipStream_t s) {
+  const bool res_f32 = rk == 2;
+  static const int meas = getenv("AGZ_C16_MEAS") ? atoi(getenv("AGZ_C16_MEAS")) : 0;
+  static bool policy_set = false;
+  if (!policy_set) {
+    policy_set = true;
+    const unsigned pm = getenv("AGZ_C16_POLICY") ? (unsigned)strtoul(getenv("AGZ_C16_POLICY"), nullptr, 0) : 0u;
+    if (pm) AGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_c16_policy), &pm, sizeof(pm)));
+  }
+  if (meas && rk == 0 && !out_f32) {
+    const int g7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
+#define AGZ_C16_MEAS_LAUNCH(MASK)                                                                                                    \
+  hipLaunchKernelGGL((k_conv3x3_f16_w2<0, 0, false, W2_RB_PRODUCT, false, false, MASK>), dim3(g7), dim3(256), 0, s, xh, wi, scale, shift, res, \
+                     y, d_count, N, relu)
+    switch (meas) {
+      case 32: AGZ_C16_MEAS_LAUNCH(32); return true;
+      case 96: AGZ_C16_MEAS_LAUNCH(96); return true;
+      case 224: AGZ_C16_MEAS_LAUNCH(224); return true;
+      case 480: AGZ_C16_MEAS_LAUNCH(480); return true;
+      default: break;
+    }
+#undef AGZ_C16_MEAS_LAUNCH
+  }
+  static const int quad = getenv("AGZ_C16_Q") ? atoi(getenv("AGZ_C16_Q")) : 1;
+  if (quad && !res_f32 && !out_f32 && (quad == 1 || !res)) {
+    static const bool qz = getenv("AGZ_C16_QZ") && atoi(getenv("AGZ_C16_QZ")) != 0;
+    if (!qz) return false;                                  // the product's own 2 x 2 launch
+    const int gq = std::min((int)((rows + QM - 1) / QM), ncu);
+    if (res) hipLaunchKernelGGL((k_conv3x3_f16_q<1, true>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)res, (_Float16*)y, d_count, N, relu);
+    else hipLaunchKernelGGL((k_conv3x3_f16_q<0, true>), dim3(gq), dim3(256), 0, s, xh, wi, scale, shift, (const _Float16*)nullptr, (_Float16*)y, d_count, N, relu);
+    return true;
+  }
+  const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
+  static const bool zb = getenv("AGZ_C16_DM") && atoi(getenv("AGZ_C16_DM")) != 0;
+#define AGZ_C16_W2(D, R, OF, RB, G)                                                                                                      \
+  do {                                                                                                                                   \
+    if (zb && (D) == 0)                                                                                                                  \
+      hipLaunchKernelGGL((k_conv3x3_f16_w2<0, R, OF, RB, AGZ_C16_WL, true>), dim3(G), dim3(256), 0, s, xh, wi, scale, shift, res, y,    \
+                         d_count, N, relu);                                                                                              \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((k_conv3x3_f16_w2<D, R, OF, RB, AGZ_C16_WL, false>), dim3(G), dim3(256), 0, s, xh, wi, scale, shift, res, y,   \
+                         d_count, N, relu);                                                                                              \
+  } while (0)
+#define AGZ_C16_W2D(D, RB, G)                          \
+  do {                                                 \
+    if (out_f32) {                                     \
+      if (rk == 0) AGZ_C16_W2(D, 0, true, RB, G);      \
+      else if (rk == 1) AGZ_C16_W2(D, 1, true, RB, G); \
+      else AGZ_C16_W2(D, 2, true, RB, G);              \
+    } else {                                           \
+      if (rk == 0) AGZ_C16_W2(D, 0, false, RB, G);     \
+      else if (rk == 1) AGZ_C16_W2(D, 1, false, RB, G);\
+      else AGZ_C16_W2(D, 2, false, RB, G);             \
+    }                                                  \
+  } while (0)
+  static const int dbg = getenv("AGZ_C16_DEBUG") ? atoi(getenv("AGZ_C16_DEBUG")) : 0;
+  static bool pace_set = false;
+  if (!pace_set) {
+    pace_set = true;
+    const unsigned pm = getenv("AGZ_C16_PACE") ? (unsigned)strtoul(getenv("AGZ_C16_PACE"), nullptr, 0) : 0u;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_c16_pace), &pm, sizeof(pm));
+  }
+  static const int rb = getenv("AGZ_C16_RB") ? atoi(getenv("AGZ_C16_RB")) : W2_RB_PRODUCT;
+  if (rb == 4) {
+    AGZ_C16_W2D(0, 4, std::min((int)((rows + 127) / 128), 2 * ncu));
+    return true;
+  }
+  switch (dbg) {
+    case 1: AGZ_C16_W2D(1, W2_RB_PRODUCT, grid7); return true;
+    case 3: AGZ_C16_W2D(3, W2_RB_PRODUCT, grid7); return true;
+    case 5: AGZ_C16_W2D(5, W2_RB_PRODUCT, grid7); return true;
+    case 9: AGZ_C16_W2D(9, W2_RB_PRODUCT, grid7); return true;
+    case 15: AGZ_C16_W2D(15, W2_RB_PRODUCT, grid7); return true;
+    case 32: AGZ_C16_W2D(32, W2_RB_PRODUCT, grid7); return true;
+    case 16: AGZ_C16_W2D(16, W2_RB_PRODUCT, grid7); return true;
+    case 48: AGZ_C16_W2D(48, W2_RB_PRODUCT, grid7); return true;
+    case 64: AGZ_C16_W2D(64, W2_RB_PRODUCT, grid7); return true;
+    case 128: AGZ_C16_W2D(128, W2_RB_PRODUCT, grid7); return true;
+    case 256: AGZ_C16_W2D(256, W2_RB_PRODUCT, grid7); return true;
+    case 512: AGZ_C16_W2D(512, W2_RB_PRODUCT, grid7); return true;
+    case 1024: AGZ_C16_W2D(1024, W2_RB_PRODUCT, grid7); return true;
+    case 1536: AGZ_C16_W2D(1536, W2_RB_PRODUCT, grid7); return true;
+    case 544: AGZ_C16_W2D(544, W2_RB_PRODUCT, grid7); return true;
+    case 34: AGZ_C16_W2D(34, W2_RB_PRODUCT, grid7); return true;
+    case 2: AGZ_C16_W2D(2, W2_RB_PRODUCT, grid7); return true;
+    default: break;
+  }
+  if (zb || !quad || (quad == 2 && res)) {                  // a non-product form of a product layer
+    AGZ_C16_W2D(0, W2_RB_PRODUCT, grid7);
+    return true;
+  }
+#undef AGZ_C16_W2D
+#undef AGZ_C16_W2
+  return false;
+}
+#endif
+
 void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale, const float* shift, const void* res,
                        int res_f32, void* y, int out_f32, const int* d_count, int bcap, int N, int relu, hipStream_t s) {
   const long rows = (long)bcap * N * N;
@@ -671,6 +991,11 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   static int ncu = 0;
   if (!ncu) AGZ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
   const int rk = !res ? 0 : (res_f32 ? 2 : 1);
+#ifdef AGZ_TIMING_EXPERIMENTS
+  // Everything an environment variable can select lives in this block: timing builds only (make EXTRA=-DAGZ_TIMING_EXPERIMENTS).
+  // The product library reads no AGZ_C16_* variable and holds none of these instantiations (tests/test_build_invariants.py).
+  if (launch_conv16_experiments(xh, wi, scale, shift, res, rk, y, out_f32, d_count, rows, ncu, N, relu, s)) return;
+#endif
   // the half-in / half-out layers (38 of a tower's 40): 2 x 2 waves over a 256-row x 256-cout tile (round 5: -1.8 % per
   // configs[4] step against the 7 x 2 form in a same-box A/B, bit-identical results)
   if (!res_f32 && !out_f32) {
@@ -681,8 +1006,9 @@ void launch_conv16_dma(const uint16_t* x, const uint16_t* wi, const float* scale
   }
   // the f32-residual and f32-output layers (first and last of a tower): 7 x 2 wave tiles over 224 rows, direct epilogue
   const int grid7 = std::min((int)((rows + 32 * W2_RB_PRODUCT - 1) / (32 * W2_RB_PRODUCT)), ncu);
-#define AGZ_C16_W2(R, OF) \
-  hipLaunchKernelGGL((k_conv3x3_f16_w2<R, OF>), dim3(grid7), dim3(256), 0, s, xh, wi, scale, shift, res, y, d_count, N, relu)
+#define AGZ_C16_W2(R, OF)                                                                                                          \
+  hipLaunchKernelGGL((k_conv3x3_f16_w2<0, R, OF, W2_RB_PRODUCT, AGZ_C16_WL, false>), dim3(grid7), dim3(256), 0, s, xh, wi, scale, \
+                     shift, res, y, d_count, N, relu)
   if (out_f32) {
     if (rk == 0) AGZ_C16_W2(0, true);
     else if (rk == 1) AGZ_C16_W2(1, true);
