@@ -187,11 +187,8 @@ __global__ __launch_bounds__(256) void k_scan(View V) {
   }
 }
 
-// One workgroup of four waves per leaf slot, each wave a quarter of the leaf's (point, quad) items.  Round 6 rewrote this
-// kernel three times and timed each (bench.py's search_kernels): coalesced 1 KB store runs instead of 64 lines 128 B apart
-// (35.5 -> 34.8 us per 8192 leaves of 9x9: the stores were not the bound), four leaves per workgroup (37.3: nor the dispatch
-// rate), and this form: a lone wave walks its leaf in eleven dependent load -> store rounds, so the kernel is as long as
-// eleven memory latencies whatever the bandwidth; four waves per leaf make it three.
+// One workgroup of four waves per leaf slot, each wave a quarter of the leaf's (point, quad) items.  (Neither this, nor
+// one wave per leaf, nor four leaves per workgroup changes its 35-39 us per 8192 leaves of 9x9: see leaf_features.)
 constexpr int kWavesPerLeaf = 4;
 __global__ __launch_bounds__(kWavesPerLeaf * kWave) void k_leaf_features(View V, int g0, int slots, float* x32, float* whcn) {
   const int slot = (int)blockIdx.x;

@@ -1369,9 +1369,11 @@ AGZ_FN void leaf_features(W& w, const View& V, int g, int k, float* x32, float* 
   if (x32) {
     // The stem input row of point p is 32 floats = eight 16-byte quads: quad c < 4 holds the planes of history boards
     // 2c and 2c + 1 (own / opponent stones each), quad 4 the colour plane, quads 5..7 the padding.  Item = (point, quad),
-    // quad fastest: the 64 lanes of a wave write 1 KB of consecutive bytes per store instruction (round 6; with lane =
-    // point each store instruction touched 64 lines 128 bytes apart: 35 us per 8192 leaves of 9x9, 0.3 of the HBM rate),
-    // and a lane reads the two board bytes its quad needs instead of all eight.
+    // quad fastest: the 64 lanes of a wave write 1 KB of consecutive bytes per store instruction, and a lane reads the two
+    // board bytes its quad needs instead of all eight.  (Round 6 tried, and timed, four things on this kernel -- this store
+    // pattern against lane = point, four leaves per workgroup, four waves per leaf, streaming stores: 35-39 us per 8192
+    // leaves of 9x9 every time, 0.3 of the HBM rate in bytes.  What it waits for is the chain leaf record -> eight node
+    // boards scattered over a 14 GB pool -> store, three dependent round trips with a TLB miss each, not bandwidth.)
     struct alignas(16) Quad { float a, b, c, d; };
     Quad* dst = reinterpret_cast<Quad*>(x32);
     const int per = (P * 8 + parts - 1) / parts, lo = part * per, hi = lo + per < P * 8 ? lo + per : P * 8;
