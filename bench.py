@@ -898,6 +898,9 @@ def main():
             if solo is not None:
                 out["single_rank_same_box"] = solo
                 out["weak_scaling_efficiency"] = min(r["positions_per_s"] for r in per_rank) / solo["positions_per_s"]
+                if args.single_device_test:
+                    out["weak_scaling_note"] = (f"--single-device-test: all {world} ranks share ONE GPU, so ~1/{world} is what this "
+                                                "field should read here; it means something on one GPU per rank")
         if exchange is not None:
             out["exchange"] = exchange
         if alt is not None:

@@ -217,6 +217,12 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
     ex = d["exchange"]
     assert "error" not in ex, ex
     assert ex["consistent"] is True and ex["ms"] > 0 and ex["games_in_arena"] == sum(ex["own_games_by_rank"]) > 0
+    # the line describes itself: bytes exchanged, the same box's one-rank rate, the efficiency against it
+    assert ex["bytes"] == sum(ex["bytes_by_rank"]) > 0 and len(ex["bytes_by_rank"]) == 2
+    solo = d["single_rank_same_box"]
+    assert solo["positions_per_s"] > 0
+    assert abs(d["weak_scaling_efficiency"] - min(p["positions_per_s"] for p in d["per_rank"]) / solo["positions_per_s"]) < 1e-9
+    assert "search_kernels" in d and set(d["search_kernels"]["kernels"]) == {"k_pre", "k_expand", "k_scan", "k_leaf_features", "k_post"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -12,3 +12,4 @@ python bench.py --gpus 2 --single-device-test --steps 20 --warmup 3 > gpurun_out
 python bench.py --gpus 8 --single-device-test --games 128 --steps 10 --warmup 2 > gpurun_out/r06lines/bench_8rank_selflaunched.json 2> gpurun_out/r06lines/bench_8rank.err
 for f in gpurun_out/r06lines/*.json; do echo "$f: $(tail -1 $f | cut -c1-160)"; done
 cat gpurun_out/r06lines/bench_default.time
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" > gpurun_out/r06lines/smoke.log 2>&1; tail -1 gpurun_out/r06lines/smoke.log
