@@ -22,12 +22,12 @@ Bars (stated here; the test prints what it measures, DESIGN.md section 4 quotes 
                  measured round 6: 2.1e-5, 7.4e-4, 4.5e-3, 3.8e-3 (all of it in v; |d pi| <= 5.3e-5), network top-1 agrees >= 0.992
   games          selected move identical on >= 0.70 of the compared moves (measured 0.768), top-1 of the recorded pi identical on
                  >= 0.90 (0.949), KL(pi_f32 || pi_f16) mean <= 2e-2 nats (1.0e-2), 95th percentile <= 5e-2 (2.3e-2), mean total
-                 variation <= 0.10;
+                 variation <= 0.05 (0.017);
   control        the same comparison between two EXACT-f32 algorithms (Winograd and the direct GEMM, tensors equal to ~1e-7):
                  selected move identical on >= 0.98 (measured 0.997: the search is not chaotic -- what the fp16 tower changes, it
                  changes).  The selected move is drawn through the cdf of pi with the SAME draw in both runs
                  (mcts_play.jl:61-66), so every boundary shift in front of the drawn value changes it: the mismatch rate (0.23)
-                 is an upper bound on, not equal to, the probability mass that moved (the total variation, ~0.05).
+                 is an upper bound on, not equal to, the probability mass that moved (the total variation: 0.017 measured).
 What that means: the fp16 tower is a different player of similar strength statistics, not the same player -- its games leave
 the f32 tower's after a median of 2 moves.  That is what "mixed-precision inference" costs at 40 convolutions on these weights;
 tree PARITY claims are made for the exact-f32 path only.
@@ -46,7 +46,7 @@ pytestmark = pytest.mark.gpu
 L = orc.lib()
 N19 = 19
 DEPTH_BARS = {1: 1.5e-3, 5: 4e-3, 10: 6e-3, 20: 1e-2}
-BAR_SAME_MOVE, BAR_SAME_TOP1, BAR_KL_MEAN, BAR_KL_P95, BAR_TV_MEAN, BAR_CONTROL = 0.70, 0.90, 2e-2, 5e-2, 0.10, 0.98
+BAR_SAME_MOVE, BAR_SAME_TOP1, BAR_KL_MEAN, BAR_KL_P95, BAR_TV_MEAN, BAR_CONTROL = 0.70, 0.90, 2e-2, 5e-2, 0.05, 0.98
 
 
 def _net(tower, seed):
