@@ -406,8 +406,8 @@ def self_launch(n, single_device):
         s.close()
         return port
 
-    # The port is picked by bind-then-close: another process can take it before rank 0's store binds it.  A run
-    # whose ranks all die within 20 s without a line is started again on a new port, up to three times.
+    # The port is picked by bind-then-close: another process can take it before rank 0's store binds it.  A rank
+    # whose rendezvous fails exits with 75 (EX_TEMPFAIL); only then are the ranks started again, on a new port, up to three times.
     rc = 1
     for attempt in range(3):
         port = free_port()
@@ -434,7 +434,7 @@ def self_launch(n, single_device):
             return 0
         # a child killed by a signal reports a negative code: the launcher's own status is 1 for any failure
         rc = 1
-        if not (failed and time.time() - t_start < 20.0):
+        if 75 not in codes:
             break                                                      # not a rendezvous failure: do not run the bench twice
         print(f"bench.py: ranks exited with {codes} after {time.time() - t_start:.0f} s (port {port}); retrying on a new port",
               file=sys.stderr)
@@ -518,11 +518,19 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.single_device_test:
-            dist.init_process_group("gloo")
-            rdev = "cpu"
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            if args.single_device_test:
+                dist.init_process_group("gloo")
+                rdev = "cpu"
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        except Exception as ex:
+            if os.environ.get("AGZ_BENCH_SELF_LAUNCHED") == "1":
+                # the self-launcher picked MASTER_PORT by bind-then-close: if somebody took it meanwhile, say so with a status
+                # the launcher recognises (EX_TEMPFAIL) and it starts the ranks again on another port
+                print(f"bench.py: rendezvous failed on rank {rank}: {type(ex).__name__}: {ex}", file=sys.stderr)
+                sys.exit(75)
+            raise
 
     N, tower, R = args.board, args.tower, args.readouts
     eng = ag.Engine(board_size=N, tower_height=tower, games=args.games, num_readouts=R, parallel_readouts=8,
