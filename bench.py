@@ -411,7 +411,6 @@ def self_launch(n, single_device):
     rc = 1
     for attempt in range(3):
         port = free_port()
-        t_start = time.time()
         procs = []
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -419,11 +418,11 @@ def self_launch(n, single_device):
                        AGZ_BENCH_SELF_LAUNCHED="1")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           stdout=None if r == 0 else sys.stderr))
-        failed, deadline = False, None
+        deadline = None
         while any(p.poll() is None for p in procs):
             for p in procs:
                 if p.poll() not in (None, 0) and deadline is None:
-                    failed, deadline = True, time.time() + 30.0        # one rank died: the others get 30 s to follow
+                    deadline = time.time() + 30.0                      # one rank died: the others get 30 s to follow
             if deadline is not None and time.time() > deadline:
                 for p in procs:                                        # (exactly the processes started above)
                     if p.poll() is None:
@@ -436,8 +435,7 @@ def self_launch(n, single_device):
         rc = 1
         if 75 not in codes:
             break                                                      # not a rendezvous failure: do not run the bench twice
-        print(f"bench.py: ranks exited with {codes} after {time.time() - t_start:.0f} s (port {port}); retrying on a new port",
-              file=sys.stderr)
+        print(f"bench.py: rendezvous failed (ranks exited with {codes}, port {port}); starting them again on a new port", file=sys.stderr)
     return rc
 
 
