@@ -57,6 +57,9 @@ constexpr int W5VSTAGE = 13 * W5T * 8;       // floats of one stage image of V (
 constexpr int W5IMG = W5T * 9 * W5H;         // floats of the half tile image: 147,456 B
 constexpr int W5PIECES = (W5SV + W5SU) / 256;      // 30 DMA pieces of 1 KB per super-stage
 static_assert(kWinoStages == 64 && kC == 256 && W5PIECES == 30, "stage structure of agz_wino.hip");
+// (W5_DIST = 3 -- four stage buffers, pieces requested three super-stages ahead -- and W5_LA = 4 -- operands read four units
+// ahead through a ring of five register sets -- were built and measured on the bench command, same box, alternating: +0.7 %
+// and +2.7 % per step; profiles/r06_ab_wino5_prefetch_distance_2_vs_3.txt, r06_ab_wino5_lookahead_1_vs_4.txt)
 #ifndef W5_DIST
 #define W5_DIST 2
 #endif
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void k_wino5_gemm(
     }
   // Residual half-tile -> image by LDS-DMA: instruction i = wave + 4 n (n < 36) fills image bytes 1024 i .. = points 4 i .. 4 i + 3;
   // lane = (point, unit u) fetches channel group u ^ (X & 15).  Half 0's is on its way before the K loops are through: the image
-  // lies over the stage buffers (4 x 30 KB) and 27 KB beyond them, so instructions n >= W5RN0 (image bytes beyond the ring) go out
+  // lies over the stage buffers (W5RING x 30 KB: 90 KB) and 55 KB beyond them, so instructions n >= W5RN0 (image bytes beyond the ring) go out
   // behind pass 3 and land during pass 4, the others when pass 4's K loop has ended -- in front of its fold, which covers part of
   // their flight (the first build waited 6 us per workgroup for a residual requested after the last fold: trace).
   auto rdma = [&](int n, int hh) {
