@@ -30,6 +30,8 @@ def child(args):
     eng = ag.Engine(board_size=args.board, tower_height=4, games=1, num_readouts=1, max_nodes_per_game=8)
     eng.init_synthetic(0)
     eng.set_precision(args.precision)
+    if args.winograd != 1:
+        eng.set_winograd(args.winograd)                # (3: the five-pass 64 x 128 form of F(3x3,3x3), agz_wino5.hip)
     eng.time_conv(args.batch, 20)                      # warm-up (packs, allocations, clocks)
     sampler = bench.PowerSampler(0).start()
     t0, ms, n = time.perf_counter(), [], 0
@@ -56,6 +58,7 @@ def main():
     ap.add_argument("--variants", nargs="+", default=["0"])
     ap.add_argument("--extra-env", nargs="*", default=[], help="NAME=VALUE pairs set for every variant")
     ap.add_argument("--swap", action="store_true", help="run with gpurun_ab/libagz_T.so in place of libagz.so")
+    ap.add_argument("--winograd", type=int, default=1)
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -69,7 +72,7 @@ def main():
         for v in args.variants:
             env = dict(os.environ, **{args.env: str(v)}, **dict(kv.split("=", 1) for kv in args.extra_env))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--precision", args.precision, "--board",
-                                str(args.board), "--batch", str(args.batch), "--seconds", str(args.seconds)],
+                                str(args.board), "--batch", str(args.batch), "--seconds", str(args.seconds), "--winograd", str(args.winograd)],
                                env=env, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if not line:
@@ -86,7 +89,7 @@ def main():
     finally:
         if args.swap:
             shutil.copy(keep, lib)
-    print(json.dumps({"precision": args.precision, "board": args.board, "batch": args.batch, "switch": args.env,
+    print(json.dumps({"precision": args.precision, "board": args.board, "batch": args.batch, "switch": args.env, "winograd": args.winograd,
                       "extra_env": args.extra_env, "rows": rows}))
     for r in rows:
         if "error" in r:
