@@ -26,7 +26,7 @@
 //                 i.e. the CU's whole 512 KB register file is the tile -- four waves, one per SIMD, 400
 //                 accumulator registers each.  Inverse transform, BatchNorm affine, residual, ReLU and the NEXT
 //                 layer's input transform follow in the epilogue: M is never written to memory.
-// Stage = 4 input channels x {64 tiles + 64 couts} x 25 planes = 52 KB, triple-buffered in LDS and filled by
+// Stage = 4 input channels x {64 tiles + 64 couts} x 25 planes = 50 KB (in a 52 KB image: one padding chunk per operand), triple-buffered in LDS and filled by
 // direct global->LDS DMA (global_load_lds_dwordx4), which is why V and U are stored in HBM as ready-made,
 // bank-swizzled stage images.  64x64 per workgroup gives 16 flop per DMA byte.
 #include "agz_nn.h"
@@ -54,14 +54,12 @@ constexpr int A_STAGE = WPL * WT * 8;    // floats (26,624 B)
 constexpr int B_STAGE = WPL * WC * 8;
 constexpr int STAGE = A_STAGE + B_STAGE;  // 13,312 floats = 52 KB
 
-// U stage image (weights): [plane pair q 13][cout 64][8 dwords]; a row = [plane 2q: 4 cins | plane 2q+1: 4 cins]
-// as four 2-dword pairs, logical pair = 2*(xi & 1) + h (h = which half of the 4 channels), rotated by f(row) so
-// that the 32 rows a wave reads with one ds_read_b64 (stride 8 dwords: only 8 distinct start banks) hit 64
-// distinct banks: rows r, r+8, r+16, r+24 get distinct pair slots.
-__host__ __device__ __forceinline__ int wino_rot(int row) { return ((row >> 2) + (row >> 4)) & 3; }
-__host__ __device__ __forceinline__ int wino_pair_pos(int row, int xi, int h) {
-  return (2 * (xi & 1) + h + wino_rot(row)) & 3;
-}
+// U stage image (weights): the V layout below with cout rows for tile rows -- plane xi is chunk xi (1 KB) of the stage image.
+// Round 6 (until then: the two planes of a pair interleaved in 32-byte rows, rotated by a function of the row so that a
+// 32-row ds_read_b64 hit 64 distinct banks -- 0.19-0.21 of the LDS cycles were still conflicts).  With one plane per chunk
+// the 26th plane slot, padding nobody multiplies with, is ONE chunk of either operand, and the K loop does not fetch it:
+// 50 instead of 52 LDS-DMA pieces per stage.  The energy table prices the stream at a third of the layer's
+// joules; 3.8 % of it gone is 1 % of a step in two same-box alternating A/Bs (profiles/r06_ab_gemm4_u_relayout*.txt).
 // V stage image (activations): [plane pair q 13][plane parity 2][tile row 64][4 dwords]; the 4 dwords of a row
 // are the plane's 4 channels as two pairs, pair h at slot (h + (row >> 4)) & 1.  Row stride 4 dwords: rows r and
 // r + 16 start on the same bank and take different slots, so a 32-row ds_read_b64 is conflict-free -- and a
@@ -293,6 +291,7 @@ __device__ __forceinline__ void wino_wg(
   // address arithmetic in front of every piece cost 8 % of the K loop (2.10 -> 1.95 ms per layer)
   auto dma = [&](int st, int buf, int j) {
     const int c = 13 * wave + j;
+    if (j == 12 && (wave & 1)) return;      // chunk 25 of either operand is the 26th plane slot: padding nobody multiplies with
     const float* g = wave < 2 ? asrc + (long)st * A_STAGE + c * 256 : bsrc + (long)st * B_STAGE + (c - 26) * 256;
     if constexpr (COH) glds16s_l2(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
     else glds16s(g, (unsigned)lane * 16u, lds0 + (unsigned)(buf * STAGE + c * 256) * 4u);
@@ -327,10 +326,8 @@ __device__ __forceinline__ void wino_wg(
   f32x16 acc[WXI];
 
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
-  const int brot = wino_rot(brow);
   // per-lane float offsets of the even / odd planes' pair slots; plane xi adds (xi >> 1) * 512 floats
   const int aoff[2] = {wino_v_off(0, arow, hi), wino_v_off(1, arow, hi)};
-  const int boff[2] = {A_STAGE + brow * 8 + 2 * ((hi + brot) & 3), A_STAGE + brow * 8 + 2 * ((2 + hi + brot) & 3)};
   constexpr int LA = 4, RING = LA + 1;     // 25 % RING == 0: ring slots are compile-time within a stage
   // operands of a plane: f32 form a float2 of A and of B (the lane's two channels); split form the whole 16-byte
   // A row (hi and lo halves of 4 channels) and the lane's 8-byte hi or lo block of B
@@ -346,7 +343,7 @@ __device__ __forceinline__ void wino_wg(
       b = *reinterpret_cast<const float2*>(L + bsoff[xi & 1] + (xi >> 1) * (WC * 8));
     } else {
       a = *reinterpret_cast<const float2*>(L + aoff[xi & 1] + (xi >> 1) * (WT * 8));
-      b = *reinterpret_cast<const float2*>(L + boff[xi & 1] + (xi >> 1) * (WC * 8));
+      b = *reinterpret_cast<const float2*>(L + bsoff[xi & 1] + (xi >> 1) * (WC * 8));
     }
   };
 
@@ -394,7 +391,11 @@ __device__ __forceinline__ void wino_wg(
   };
 
   constexpr int PW = 13;      // DMA pieces per wave and stage
-  auto wait_stage = [&]() { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); };
+  // (waves 0, 2 move 13 pieces per stage, waves 1, 3 twelve: the padding chunk stays where it is)
+  auto wait_stage = [&]() {
+    if (wave & 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  };
   wait_stage();
   __syncthreads();
 #pragma unroll
@@ -846,8 +847,10 @@ __host__ __device__ inline void wino_pack_pair(const float* w, int cin, int o, i
         o16[2 * (base + wino_v_off(xi, ol, 0)) + cl] = hi;
         o16[2 * (base + wino_v_off(xi, ol, 1)) + cl] = lo;
       } else {
-        const int pos = 2 * wino_pair_pos(ol, xi, cl >> 1) + (cl & 1);
-        out[(((size_t)cb * ns + st) * WPL + (xi >> 1)) * WC * 8 + (size_t)ol * 8 + pos] = (float)u;
+        // (round 6: the layout V is stored in -- plane xi is chunk xi of the stage image, rows of 16 bytes, pair h at slot
+        // (h + (row >> 4)) & 1: conflict-free 32-row ds_read_b64, and the padding is ONE chunk that the K loop never fetches;
+        // rounds 1-5 interleaved the two planes of a pair in 32-byte rows rotated by the row: 0.2 of the LDS cycles in conflicts)
+        out[((size_t)cb * ns + st) * B_STAGE + wino_v_off(xi, ol, cl >> 1) + (cl & 1)] = (float)u;
       }
     }
 }
