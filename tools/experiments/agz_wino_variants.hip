@@ -1,3 +1,7 @@
+// FROZEN COPY of alphago.jl_amd/csrc/agz_wino.hip as it was in round 6 BEFORE its U operand moved to V's one-plane-per-chunk
+// layout (commit cabb700): the product file with every timing variant (template parameter X), wall-clock stamp, the RESPF and
+// PROLOGUE_STAMP builds and the trace dumps.  tools/build_timing_lib.sh compiles it in place of the product file (ALSO=agz_wino);
+// pack and kernels are one translation unit, so the old layout is self-consistent here.  Results of X != 0 are WRONG by design.
 // agz_wino.hip -- the 3x3 256->256 tower convolution as Winograd F(3x3, 3x3) on the f32 MFMA.
 //
 // Why: the direct implicit GEMM (agz_nn.hip) is bound by the exact-f32 MFMA rate (157 TFLOP/s,
